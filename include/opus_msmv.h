@@ -1,0 +1,118 @@
+/*
+ * opus_msmv.h - C ABI of libopus_msmv.so: multi-scale multi-view feature sampling
+ * (forward + backward) for MI355X / gfx950.
+ *
+ * This is the drop-in boundary for the native half of the reference's sampling op.  The
+ * reference binds four pybind11 functions (models/csrc/msmv_sampling/msmv_sampling.cpp:362-368)
+ * over raw-pointer launchers (msmv_sampling.cpp:5-96); the entry points below take the
+ * same raw pointers and sizes, with the level count as a runtime argument instead of a
+ * _c2345 / _c23456 suffix, an explicit stream, and an error code instead of a printf.
+ *
+ * Conventions
+ *   - All tensors are fp32, contiguous, resident on the device that is current when the
+ *     call is made.  Nothing is allocated, freed or synchronised inside the library; the
+ *     launches are asynchronous on `stream` (a hipStream_t passed as void*, NULL = the
+ *     default stream).  The library keeps no state between calls and is thread-safe.
+ *   - feats[l]  : [B, N, H_l, W_l, C]  channel-last   (msmv_sampling.cpp:99-102)
+ *     loc       : [B, Q, P, 3]  (x/width, y/height, view/(N-1)), each nominally in [0,1]
+ *     weights   : [B, Q, P, L]
+ *     out       : [B, Q, C, P]                       (msmv_sampling.cpp:136)
+ *   - `feats` / `dfeats` are HOST arrays of L device pointers; `hw` is a HOST array of
+ *     2*L ints {H_0, W_0, H_1, W_1, ...}.
+ *   - Return value: OPUS_MSMV_OK (0) or a negative OPUS_MSMV_E* code; text via
+ *     opus_msmv_strerror().
+ */
+#ifndef OPUS_MSMV_H
+#define OPUS_MSMV_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPUS_MSMV_VERSION 100          /* major*10000 + minor*100 + patch */
+#define OPUS_MSMV_MAX_LEVELS 8
+#define OPUS_MSMV_MAX_POINTS 32        /* MAX_POINT, msmv_sampling_forward.cu:21, msmv_sampling.cpp:125 */
+
+enum {
+    OPUS_MSMV_OK = 0,
+    OPUS_MSMV_EINVAL_LEVELS = -1,   /* L outside [1, OPUS_MSMV_MAX_LEVELS] */
+    OPUS_MSMV_EINVAL_POINTS = -2,   /* P outside [1, 32]: "num_point exceed limits" (msmv_sampling.cpp:125) */
+    OPUS_MSMV_EINVAL_DIMS = -3,     /* a negative size, or zero C / N / H / W */
+    OPUS_MSMV_EINVAL_PTR = -4,      /* a NULL pointer where data is required */
+    OPUS_MSMV_ETOOLARGE = -5,       /* B*Q*P*C or a feature slab count exceeds the 31-bit point index */
+    OPUS_MSMV_EWORKSPACE = -6,      /* workspace missing or smaller than opus_msmv_backward_workspace_bytes() */
+    OPUS_MSMV_EINVAL_FLAGS = -7,    /* unknown algorithm / flag combination */
+    OPUS_MSMV_ELAUNCH = -8          /* hipGetLastError() != hipSuccess after a launch */
+};
+
+/* backward algorithm selector (low 4 bits of `flags`) */
+enum {
+    OPUS_MSMV_BWD_AUTO = 0,      /* owner-computes where it applies (C == 64), else atomic scatter */
+    OPUS_MSMV_BWD_ATOMIC = 1,    /* wave-reduced dloc/dw + fp32 atomics into d feats (zero-filled first) */
+    OPUS_MSMV_BWD_OWNER = 2      /* every d-feat tile is accumulated in LDS by one workgroup: no atomics, no zero-fill */
+};
+/* OR-ed into `flags`: do not clear d feats first, add onto their current contents
+ * (atomic algorithm only).  The reference always clears (msmv_sampling.cpp:244-247). */
+#define OPUS_MSMV_BWD_ACCUMULATE 0x10
+
+/* Library version (OPUS_MSMV_VERSION it was built with). */
+int opus_msmv_version(void);
+
+/* Text for a return code; never NULL. */
+const char *opus_msmv_strerror(int code);
+
+/*
+ * Forward: out[b,q,c,p] = sum_l weights[b,q,p,l] * bilinear(feats[l][b, view(b,q,p)], x, y)[c]
+ * with align_corners=True pixel mapping, zero padding per corner, view = round(loc_v*(N-1)).
+ * Replaces ms_deform_attn_cuda_c2345_forward / _c23456_forward
+ * (msmv_sampling.cpp:98-150, :152-210; kernels msmv_sampling_forward.cu:75-164, :166-267).
+ * Every element of `out` is written.  A view index outside [0, N-1] (undefined behaviour
+ * in the reference) contributes zero.
+ */
+int opus_msmv_forward(int L, const float *const *feats, const int *hw,
+                      const float *loc, const float *weights,
+                      int B, int C, int N, int Q, int P,
+                      float *out, void *stream);
+
+/*
+ * Same as opus_msmv_forward with a flags word.  OPUS_MSMV_FWD_GENERIC selects the
+ * any-shape kernel even where the specialised one (C == 64, L in {4,5}, 16-byte aligned
+ * pointers) applies; it exists so that tests can cover both kernels on one input.  No
+ * counterpart in the reference.
+ */
+#define OPUS_MSMV_FWD_GENERIC 0x1
+int opus_msmv_forward_ex(int L, const float *const *feats, const int *hw,
+                         const float *loc, const float *weights,
+                         int B, int C, int N, int Q, int P,
+                         float *out, int flags, void *stream);
+
+/*
+ * Bytes of device scratch the backward call needs for these sizes and `flags`
+ * (0 for the atomic algorithm).  Has no counterpart in the reference, whose backward
+ * needs no scratch.
+ */
+size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int P, int flags);
+
+/*
+ * Backward of the above for a given grad_out [B,Q,C,P] (contiguous).  Writes
+ *   dfeats[l] [B,N,H_l,W_l,C]  - completely (cleared + accumulated; see ACCUMULATE),
+ *   dloc      [B,Q,P,3]        - x and y gradients; the view slot is written 0,
+ *   dweights  [B,Q,P,L].
+ * Replaces ms_deform_attn_cuda_c2345_backward / _c23456_backward (msmv_sampling.cpp:212-281,
+ * :283-360; kernels msmv_sampling_backward.cu:108-224, :226-361), including the
+ * zeros_like() clears the reference's host shim performs (msmv_sampling.cpp:244-249).
+ * `workspace` must point to at least opus_msmv_backward_workspace_bytes(...) bytes of
+ * device memory (may be NULL when that is 0); its contents on entry are ignored.
+ */
+int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, const int *hw,
+                       const float *loc, const float *weights,
+                       int B, int C, int N, int Q, int P,
+                       float *const *dfeats, float *dloc, float *dweights,
+                       void *workspace, size_t workspace_bytes, int flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPUS_MSMV_H */

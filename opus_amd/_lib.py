@@ -1,0 +1,81 @@
+"""ctypes binding of libopus_msmv.so (declared in include/opus_msmv.h).
+
+This replaces the reference's pybind11 module ``_msmv_sampling_cuda``
+(models/csrc/msmv_sampling/msmv_sampling.cpp:362-368): the same four operations, taken
+through a plain C ABI with raw device pointers, sizes and the current HIP stream.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libopus_msmv.so")
+
+OK = 0
+BWD_AUTO, BWD_ATOMIC, BWD_OWNER = 0, 1, 2
+BWD_ACCUMULATE = 0x10
+FWD_GENERIC = 0x1
+MAX_LEVELS = 8
+MAX_POINTS = 32
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); every symbol include/opus_msmv.h declares
+SYMBOLS = {
+    "opus_msmv_version": (ctypes.c_int, []),
+    "opus_msmv_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "opus_msmv_forward": (ctypes.c_int, [
+        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _i32p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p]),
+    "opus_msmv_forward_ex": (ctypes.c_int, [
+        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _i32p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "opus_msmv_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
+    "opus_msmv_backward": (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), _i32p,
+        ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C opus_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:            # missing libamdhip64 etc.
+            raise ImportError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (restype, argtypes) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def strerror(code):
+    return load().opus_msmv_strerror(code).decode()
+
+
+def check(code, what):
+    if code != OK:
+        raise RuntimeError(f"{what}: {strerror(code)} (code {code})")
+
+
+def ptr_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def int_array(vals):
+    return (ctypes.c_int * len(vals))(*vals)

@@ -1,0 +1,194 @@
+// C ABI of libopus_msmv.so (see include/opus_msmv.h): argument validation, the kernel
+// argument block, and dispatch to the launchers.  No allocation, no synchronisation, no
+// global state.
+#include "../../include/opus_msmv.h"
+#include "msmv_launch.h"
+
+#include <limits.h>
+#include <stdint.h>
+
+namespace {
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Validates sizes and fills everything in MsmvArgs except the data pointers.
+int fill_common(MsmvArgs &a, int L, const int *hw, int B, int C, int N, int Q, int P)
+{
+    if (L < 1 || L > OPUS_MSMV_MAX_LEVELS)
+        return OPUS_MSMV_EINVAL_LEVELS;
+    if (P < 1 || P > OPUS_MSMV_MAX_POINTS)
+        return OPUS_MSMV_EINVAL_POINTS;
+    if (B < 0 || Q < 0 || C < 1 || N < 1)
+        return OPUS_MSMV_EINVAL_DIMS;
+    if (!hw)
+        return OPUS_MSMV_EINVAL_PTR;
+    for (int l = 0; l < L; ++l) {
+        if (hw[2 * l] < 1 || hw[2 * l + 1] < 1)
+            return OPUS_MSMV_EINVAL_DIMS;
+        if ((long long)hw[2 * l] * hw[2 * l + 1] > INT_MAX / 64)
+            return OPUS_MSMV_ETOOLARGE;
+        a.lvl[l].H = hw[2 * l];
+        a.lvl[l].W = hw[2 * l + 1];
+    }
+    // point indices and grad_out element offsets are 31-bit inside the kernels
+    const long long npts = (long long)B * Q * P;
+    if (npts * (long long)(C > L ? C : L) > INT_MAX || (long long)B * N > INT_MAX)
+        return OPUS_MSMV_ETOOLARGE;
+    a.L = L; a.B = B; a.C = C; a.N = N; a.Q = Q; a.P = P;
+    a.npts = (int)npts;
+    a.qp = Q * P;
+    a.qp_magic = 0;
+    a.qp_shift = 0;
+    if (a.qp >= 2) {
+        int l2 = 0;
+        while ((1ll << l2) < a.qp)
+            ++l2;                                            // ceil(log2(qp)), >= 1
+        const unsigned __int128 one = 1;
+        const unsigned __int128 num = one << (31 + l2);
+        a.qp_magic = (uint32_t)((num + (unsigned)a.qp - 1) / (unsigned)a.qp);
+        a.qp_shift = (uint32_t)(l2 - 1);
+    }
+    return OPUS_MSMV_OK;
+}
+
+int owner_applicable(const MsmvArgs &a, const float *gout)
+{
+    if (!msmv_backward_owner_supported(a) || !aligned16(gout))
+        return 0;
+    for (int l = 0; l < a.L; ++l)
+        if (!aligned16(a.lvl[l].feat) || !aligned16(a.lvl[l].dfeat))
+            return 0;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int opus_msmv_version(void) { return OPUS_MSMV_VERSION; }
+
+const char *opus_msmv_strerror(int code)
+{
+    switch (code) {
+    case OPUS_MSMV_OK: return "ok";
+    case OPUS_MSMV_EINVAL_LEVELS: return "number of feature levels must be in [1, 8]";
+    case OPUS_MSMV_EINVAL_POINTS: return "num_point exceed limits (must be in [1, 32])";
+    case OPUS_MSMV_EINVAL_DIMS: return "invalid tensor dimensions";
+    case OPUS_MSMV_EINVAL_PTR: return "null pointer argument";
+    case OPUS_MSMV_ETOOLARGE: return "problem too large for 31-bit point / element indices";
+    case OPUS_MSMV_EWORKSPACE: return "workspace missing or too small (see opus_msmv_backward_workspace_bytes)";
+    case OPUS_MSMV_EINVAL_FLAGS: return "unknown algorithm or flag combination";
+    case OPUS_MSMV_ELAUNCH: return "HIP kernel launch failed";
+    default: return "unknown error code";
+    }
+}
+
+int opus_msmv_forward_ex(int L, const float *const *feats, const int *hw,
+                         const float *loc, const float *weights,
+                         int B, int C, int N, int Q, int P,
+                         float *out, int flags, void *stream)
+{
+    MsmvArgs a = {};
+    const int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    if (rc != OPUS_MSMV_OK)
+        return rc;
+    if (flags & ~OPUS_MSMV_FWD_GENERIC)
+        return OPUS_MSMV_EINVAL_FLAGS;
+    if (a.npts == 0)
+        return OPUS_MSMV_OK;
+    if (!feats || !loc || !weights || !out)
+        return OPUS_MSMV_EINVAL_PTR;
+    bool fast_ok = aligned16(out) && aligned16(weights);
+    for (int l = 0; l < L; ++l) {
+        if (!feats[l])
+            return OPUS_MSMV_EINVAL_PTR;
+        a.lvl[l].feat = feats[l];
+        fast_ok = fast_ok && aligned16(feats[l]);
+    }
+    a.loc = loc;
+    a.w = weights;
+    a.out = out;
+    const int generic = (flags & OPUS_MSMV_FWD_GENERIC) || !fast_ok;
+    return msmv_launch_forward(a, (hipStream_t)stream, generic) == hipSuccess ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
+}
+
+int opus_msmv_forward(int L, const float *const *feats, const int *hw,
+                      const float *loc, const float *weights,
+                      int B, int C, int N, int Q, int P,
+                      float *out, void *stream)
+{
+    return opus_msmv_forward_ex(L, feats, hw, loc, weights, B, C, N, Q, P, out, 0, stream);
+}
+
+size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int P, int flags)
+{
+    const int algo = flags & 0xF;
+    if (algo == OPUS_MSMV_BWD_ATOMIC || (flags & OPUS_MSMV_BWD_ACCUMULATE))
+        return 0;
+    if (L < 1 || B < 0 || N < 1 || Q < 0 || P < 1)
+        return 0;
+    MsmvArgs a = {};
+    a.C = C; a.L = L;
+    if (!msmv_backward_owner_supported(a))
+        return 0;
+    return msmv_backward_owner_workspace(B, N, Q, P);
+}
+
+int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, const int *hw,
+                       const float *loc, const float *weights,
+                       int B, int C, int N, int Q, int P,
+                       float *const *dfeats, float *dloc, float *dweights,
+                       void *workspace, size_t workspace_bytes, int flags, void *stream)
+{
+    MsmvArgs a = {};
+    const int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    if (rc != OPUS_MSMV_OK)
+        return rc;
+    const int algo = flags & 0xF;
+    const bool accumulate = (flags & OPUS_MSMV_BWD_ACCUMULATE) != 0;
+    if ((flags & ~(0xF | OPUS_MSMV_BWD_ACCUMULATE)) || algo > OPUS_MSMV_BWD_OWNER)
+        return OPUS_MSMV_EINVAL_FLAGS;
+    if (accumulate && algo == OPUS_MSMV_BWD_OWNER)
+        return OPUS_MSMV_EINVAL_FLAGS;
+    if (!feats || !dfeats)
+        return OPUS_MSMV_EINVAL_PTR;
+    for (int l = 0; l < L; ++l) {
+        if (B > 0 && (!feats[l] || !dfeats[l]))
+            return OPUS_MSMV_EINVAL_PTR;
+        a.lvl[l].feat = feats[l];
+        a.lvl[l].dfeat = dfeats[l];
+    }
+    if (a.npts > 0 && (!grad_out || !loc || !weights || !dloc || !dweights))
+        return OPUS_MSMV_EINVAL_PTR;
+    a.loc = loc;
+    a.w = weights;
+    a.gout = grad_out;
+    a.dloc = dloc;
+    a.dw = dweights;
+    if (B == 0)
+        return OPUS_MSMV_OK;
+
+    bool use_owner;
+    if (algo == OPUS_MSMV_BWD_OWNER) {
+        if (!owner_applicable(a, grad_out))
+            return OPUS_MSMV_EINVAL_FLAGS;
+        use_owner = true;
+    } else if (algo == OPUS_MSMV_BWD_ATOMIC || accumulate) {
+        use_owner = false;
+    } else {
+        use_owner = owner_applicable(a, grad_out) != 0;
+    }
+
+    hipError_t e;
+    if (use_owner) {
+        const size_t need = msmv_backward_owner_workspace(B, N, Q, P);
+        if (!workspace || workspace_bytes < need || !aligned16(workspace))
+            return OPUS_MSMV_EWORKSPACE;
+        e = msmv_launch_backward_owner(a, workspace, (hipStream_t)stream);
+    } else {
+        e = msmv_launch_backward_atomic(a, (hipStream_t)stream, accumulate);
+    }
+    return e == hipSuccess ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
+}
+
+}  // extern "C"

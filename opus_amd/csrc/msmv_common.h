@@ -1,0 +1,132 @@
+// Shared device-side definitions of the msmv sampling kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MSMV_MAX_LEVELS 8
+#define MSMV_WAVE 64
+
+struct MsmvLevel {
+    const float *feat;   // [B, N, H, W, C]
+    float *dfeat;        // same shape (backward only)
+    int H, W;
+};
+
+// Passed by value as the kernel argument block.
+struct MsmvArgs {
+    MsmvLevel lvl[MSMV_MAX_LEVELS];
+    const float *loc;      // [B, Q, P, 3]
+    const float *w;        // [B, Q, P, L]
+    float *out;            // forward: [B, Q, C, P]
+    const float *gout;     // backward: grad of out
+    float *dloc;           // [B, Q, P, 3]
+    float *dw;             // [B, Q, P, L]
+    int L, B, C, N, Q, P;
+    int npts;              // B*Q*P  (host guarantees < 2^31)
+    int qp;                // Q*P
+    uint32_t qp_magic;     // floor-division of a point index by Q*P without a divide:
+    uint32_t qp_shift;     //   pt / qp == umulhi(pt, qp_magic) >> qp_shift   (pt < 2^31)
+};
+
+// pt / (Q*P) for 0 <= pt < 2^31.  For d = Q*P >= 2 the host sets l = ceil(log2 d),
+// qp_magic = ceil(2^(31+l) / d) (< 2^32) and qp_shift = l - 1, which is exact for every
+// 31-bit numerator; d = 1 has no 32-bit magic and is handled by the comparison.
+__device__ __forceinline__ int msmv_batch_of(int pt, const MsmvArgs &a)
+{
+    return a.qp == 1 ? pt : (int)(__umulhi((uint32_t)pt, a.qp_magic) >> a.qp_shift);
+}
+
+// One bilinear tap of one level: geometry shared by all channels of a point.
+// Mirrors the arithmetic of the reference tap (msmv_sampling_forward.cu:32-69):
+// align_corners=True pixel coordinates, floor, per-corner zero padding.
+struct MsmvTap {
+    float w1, w2, w3, w4;   // hh*hw, hh*lw, lh*hw, lh*lw  with invalid corners' weights as computed (not zeroed)
+    float lh, lw, hh, hw;
+    int o1, o2, o3, o4;     // pixel offsets (h*W + w) of the four corners, clamped into the slab
+    bool ok;                // level in range: -1 < h_im < H and -1 < w_im < W
+    bool c1, c2, c3, c4;    // corner inside the image
+};
+
+__device__ __forceinline__ MsmvTap msmv_make_tap(float loc_w, float loc_h, int H, int W, bool view_ok)
+{
+    MsmvTap t;
+    float h_im = loc_h * (float)(H - 1);
+    float w_im = loc_w * (float)(W - 1);
+    // NaN compares false, so a NaN location is out of range like in the reference (forward.cu:126)
+    t.ok = view_ok && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+    h_im = t.ok ? h_im : 0.f;
+    w_im = t.ok ? w_im : 0.f;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h_low = (int)hf, w_low = (int)wf;
+    t.lh = h_im - hf;
+    t.lw = w_im - wf;
+    t.hh = 1.f - t.lh;
+    t.hw = 1.f - t.lw;
+    const bool top = h_low >= 0, left = w_low >= 0;
+    const bool bot = h_low + 1 <= H - 1, right = w_low + 1 <= W - 1;
+    t.c1 = t.ok && top && left;
+    t.c2 = t.ok && top && right;
+    t.c3 = t.ok && bot && left;
+    t.c4 = t.ok && bot && right;
+    const int r0 = top ? h_low : 0, r1 = bot ? h_low + 1 : H - 1;
+    const int q0 = left ? w_low : 0, q1 = right ? w_low + 1 : W - 1;
+    t.o1 = r0 * W + q0;
+    t.o2 = r0 * W + q1;
+    t.o3 = r1 * W + q0;
+    t.o4 = r1 * W + q1;
+    t.w1 = t.hh * t.hw;
+    t.w2 = t.hh * t.lw;
+    t.w3 = t.lh * t.hw;
+    t.w4 = t.lh * t.lw;
+    return t;
+}
+
+// view index of a point: round-half-away-from-zero of loc_v*(N-1) (forward.cu:110).
+// Returns -1 for anything that does not land in [0, N-1] (NaN, infinities, out of range):
+// the reference would index out of bounds there; such a point contributes nothing here.
+__device__ __forceinline__ int msmv_view_of(float loc_v, int N)
+{
+    const float r = roundf(loc_v * (float)(N - 1));
+    return (r >= 0.f && r < (float)N) ? (int)r : -1;
+}
+
+// ---- cross-lane sums -------------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ float msmv_dpp_add(float v)
+{
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+    return v + __int_as_float(x);
+}
+
+// Sum over each row of 16 lanes; every lane of the row ends up holding the row's sum.
+__device__ __forceinline__ float msmv_row16_sum(float v)
+{
+    v = msmv_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = msmv_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = msmv_dpp_add<0x141>(v);   // row_half_mirror
+    v = msmv_dpp_add<0x140>(v);   // row_mirror
+    return v;
+}
+
+// Sum over all 64 lanes, returned wave-uniform.
+__device__ __forceinline__ float msmv_wave_sum(float v)
+{
+    v = msmv_row16_sum(v);
+    const int x = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(x, 0)) +
+            __int_as_float(__builtin_amdgcn_readlane(x, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(x, 32)) +
+            __int_as_float(__builtin_amdgcn_readlane(x, 48)));
+}
+
+// Logical block index for a launch of `nblk` blocks such that the blocks that share an XCD
+// (observed: blockIdx % 8) work on one contiguous range of logical indices, so that one
+// batch slab's feature maps are served by one XCD's L2.  Bijective for every nblk.
+__device__ __forceinline__ int msmv_xcd_remap(int bid, int nblk)
+{
+    const int xcd = bid & 7, within = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + within;
+}

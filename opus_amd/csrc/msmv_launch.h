@@ -1,0 +1,15 @@
+// Host-side launchers shared between the kernel translation units and the C ABI.
+#pragma once
+#include "msmv_common.h"
+#include <stddef.h>
+
+// force_generic != 0 selects the any-shape kernel even when the fast path applies (testing).
+hipError_t msmv_launch_forward(const MsmvArgs &a, hipStream_t s, int force_generic);
+
+// Atomic-scatter backward: clears d feats unless `accumulate`, then one wave per point.
+hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool accumulate);
+
+// Owner-computes backward (C == 64 only).
+bool msmv_backward_owner_supported(const MsmvArgs &a);
+size_t msmv_backward_owner_workspace(int B, int N, int Q, int P);
+hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s);

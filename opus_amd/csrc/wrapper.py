@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's ``models/csrc/wrapper.py`` for MI355X.
+
+Same public names and call signatures as the reference module, so that
+``from .csrc.wrapper import msmv_sampling, msmv_sampling_pytorch`` (models/opus_sampling.py:5)
+and ``from .csrc.wrapper import MSMV_CUDA`` (models/opus_transformer.py:14) keep working:
+
+    MSMV_CUDA                 True when libopus_msmv.so is loaded   (wrapper.py:4-11)
+    msmv_sampling_pytorch     channel-first grid_sample formulation  (wrapper.py:14-38)
+    MSMVSamplingC2345         autograd Function, 4 levels            (wrapper.py:41-61)
+    MSMVSamplingC23456        autograd Function, 5 levels            (wrapper.py:64-84)
+    msmv_sampling             dispatcher                             (wrapper.py:87-93)
+
+Differences, all deliberate:
+  * the native code is a C-ABI shared library reached through ctypes (opus_amd/_lib.py),
+    launched on the caller's current HIP stream and device;
+  * ``msmv_sampling`` never silently falls back: with the library missing it raises.  A
+    caller that wants the grid_sample formulation calls ``msmv_sampling_pytorch`` itself;
+  * launch failures raise ``RuntimeError`` (the reference prints and continues,
+    msmv_sampling_forward.cu:295-298);
+  * the gradient buffers are allocated here with ``torch.empty`` and fully written by the
+    library (the reference's host shim allocates zeros, msmv_sampling.cpp:244-249).
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+try:
+    _lib.load()
+    MSMV_CUDA = True
+except ImportError as e:
+    if torch.cuda.is_available():
+        # a GPU is present but the extension is not: that is a broken install, not a
+        # configuration to limp along in
+        raise
+    print('Warning: failed to load the HIP extension libopus_msmv.so; '
+          'msmv_sampling() will raise, only msmv_sampling_pytorch() is usable.')
+    print('Error message:', e)
+    MSMV_CUDA = False
+
+_BWD_ALGOS = {"auto": _lib.BWD_AUTO, "atomic": _lib.BWD_ATOMIC, "owner": _lib.BWD_OWNER}
+_bwd_algo = os.environ.get("OPUS_MSMV_BWD_ALGO", "auto")
+if _bwd_algo not in _BWD_ALGOS:
+    raise ValueError(f"OPUS_MSMV_BWD_ALGO must be one of {sorted(_BWD_ALGOS)}, got {_bwd_algo!r}")
+
+
+def set_backward_algo(name):
+    """'auto' (default), 'atomic' or 'owner' - see include/opus_msmv.h."""
+    global _bwd_algo
+    if name not in _BWD_ALGOS:
+        raise ValueError(f"unknown backward algorithm {name!r}")
+    _bwd_algo = name
+
+
+def msmv_sampling_pytorch(mlvl_feats, sampling_locations, scale_weights):
+    """grid_sample formulation on channel-FIRST features (reference wrapper.py:14-38).
+
+    mlvl_feats: list of [B, C, N, H, W]; sampling_locations [B, Q, P, 3] in [0, 1];
+    scale_weights [B, Q, P, L].  Returns [B, Q, C, P].  The view coordinate is the depth
+    axis of a trilinear sample here, whereas the device kernels round it to a view.
+    """
+    assert scale_weights.shape[-1] == len(mlvl_feats)
+    B, C = mlvl_feats[0].shape[:2]
+    _, Q, P, _ = sampling_locations.shape
+    grid = (sampling_locations * 2 - 1).unsqueeze(3)          # [B, Q, P, 1, 3]
+    total = torch.zeros([B, C, Q, P], device=mlvl_feats[0].device)
+    for lvl, feat in enumerate(mlvl_feats):
+        sampled = F.grid_sample(feat, grid, mode='bilinear', padding_mode='zeros',
+                                align_corners=True)[..., 0]   # [B, C, Q, P]
+        total += sampled * scale_weights[..., lvl].reshape(B, 1, Q, P)
+    return total.permute(0, 2, 1, 3)
+
+
+# --------------------------------------------------------------------------------------
+# argument checks (the reference's AT_ASSERTM list, msmv_sampling.cpp:106-125, plus dtype /
+# device / shape consistency, which the reference leaves unchecked)
+# --------------------------------------------------------------------------------------
+def _check_inputs(feats, loc, w):
+    if not MSMV_CUDA:
+        raise RuntimeError("libopus_msmv.so is not loaded: build it with `make -C opus_amd/csrc`")
+    L = len(feats)
+    for f in feats:
+        if not f.is_contiguous():
+            raise RuntimeError("value tensor has to be contiguous")
+        if not f.is_cuda:
+            raise RuntimeError("value must be a CUDA tensor")
+    if not loc.is_contiguous():
+        raise RuntimeError("sampling_loc tensor has to be contiguous")
+    if not w.is_contiguous():
+        raise RuntimeError("attn_weight tensor has to be contiguous")
+    if not loc.is_cuda:
+        raise RuntimeError("sampling_loc must be a CUDA tensor")
+    if not w.is_cuda:
+        raise RuntimeError("attn_weight must be a CUDA tensor")
+    dev = feats[0].device
+    for t in list(feats) + [loc, w]:
+        if t.dtype != torch.float32:
+            raise RuntimeError("msmv_sampling expects float32 tensors")
+        if t.device != dev:
+            raise RuntimeError("msmv_sampling expects all tensors on one device")
+    if feats[0].dim() != 5 or loc.dim() != 4 or w.dim() != 4 or loc.shape[-1] != 3:
+        raise RuntimeError("msmv_sampling: expected feats [B,N,H,W,C], loc [B,Q,P,3], weights [B,Q,P,L]")
+    B, N, _, _, C = feats[0].shape
+    _, Q, P, _ = loc.shape
+    if P > _lib.MAX_POINTS:
+        raise RuntimeError("num_point exceed limits")
+    for f in feats:
+        if f.dim() != 5 or f.shape[0] != B or f.shape[1] != N or f.shape[4] != C:
+            raise RuntimeError("msmv_sampling: feature levels disagree on batch, views or channels")
+    if loc.shape[0] != B or tuple(w.shape) != (B, Q, P, L):
+        raise RuntimeError("msmv_sampling: sampling_loc / attn_weight shape mismatch")
+    hw = [d for f in feats for d in f.shape[2:4]]
+    return L, B, C, N, Q, P, hw
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def msmv_forward(feats, loc, w, flags=0):
+    """Raw forward: feats channel-last [B,N,H,W,C] -> out [B,Q,C,P] (no autograd)."""
+    L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
+    out = torch.empty((B, Q, C, P), dtype=torch.float32, device=loc.device)
+    lib = _lib.load()
+    with torch.cuda.device(loc.device):
+        rc = lib.opus_msmv_forward_ex(
+            L, _lib.ptr_array([f.data_ptr() for f in feats]), _lib.int_array(hw),
+            loc.data_ptr(), w.data_ptr(), B, C, N, Q, P, out.data_ptr(), flags,
+            _stream_ptr(loc.device))
+    _lib.check(rc, "opus_msmv_forward")
+    return out
+
+
+def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None):
+    """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them."""
+    L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
+    if not grad_out.is_contiguous() or tuple(grad_out.shape) != (B, Q, C, P) \
+            or grad_out.dtype != torch.float32 or grad_out.device != loc.device:
+        raise RuntimeError("grad_output must be a contiguous float32 [B,Q,C,P] tensor on the inputs' device")
+    flags = _BWD_ALGOS[_bwd_algo if algo is None else algo]
+    if dfeats is None:
+        dfeats = [torch.empty_like(f) for f in feats]
+    else:
+        flags = _lib.BWD_ATOMIC | _lib.BWD_ACCUMULATE
+    dloc = torch.empty_like(loc)
+    dw = torch.empty_like(w)
+    lib = _lib.load()
+    with torch.cuda.device(loc.device):
+        need = lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags)
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=loc.device)
+        rc = lib.opus_msmv_backward(
+            L, grad_out.data_ptr(), _lib.ptr_array([f.data_ptr() for f in feats]),
+            _lib.int_array(hw), loc.data_ptr(), w.data_ptr(), B, C, N, Q, P,
+            _lib.ptr_array([d.data_ptr() for d in dfeats]), dloc.data_ptr(), dw.data_ptr(),
+            ws.data_ptr(), need, flags, _stream_ptr(loc.device))
+    _lib.check(rc, "opus_msmv_backward")
+    return dfeats, dloc, dw
+
+
+class _MSMVSampling(torch.autograd.Function):
+    """Any level count in [1, 8]; the two named Functions below fix it to 4 and 5."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        *feats, sampling_locations, scale_weights = args
+        ctx.save_for_backward(*feats, sampling_locations, scale_weights)
+        return msmv_forward(feats, sampling_locations, scale_weights)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        *feats, sampling_locations, scale_weights = ctx.saved_tensors
+        dfeats, dloc, dw = msmv_backward(grad_output.contiguous(), feats,
+                                         sampling_locations, scale_weights)
+        return (*dfeats, dloc, dw)
+
+
+class MSMVSamplingC2345(_MSMVSampling):
+    @staticmethod
+    def forward(ctx, feat_c2, feat_c3, feat_c4, feat_c5, sampling_locations, scale_weights):
+        return _MSMVSampling.forward(ctx, feat_c2, feat_c3, feat_c4, feat_c5,
+                                     sampling_locations, scale_weights)
+
+
+class MSMVSamplingC23456(_MSMVSampling):
+    @staticmethod
+    def forward(ctx, feat_c2, feat_c3, feat_c4, feat_c5, feat_c6, sampling_locations, scale_weights):
+        return _MSMVSampling.forward(ctx, feat_c2, feat_c3, feat_c4, feat_c5, feat_c6,
+                                     sampling_locations, scale_weights)
+
+
+def msmv_sampling(mlvl_feats, sampling_locations, scale_weights):
+    """Channel-last features [B,N,H,W,C] per level -> [B,Q,C,P] (reference wrapper.py:87-93)."""
+    if len(mlvl_feats) == 4:
+        return MSMVSamplingC2345.apply(*mlvl_feats, sampling_locations, scale_weights)
+    if len(mlvl_feats) == 5:
+        return MSMVSamplingC23456.apply(*mlvl_feats, sampling_locations, scale_weights)
+    return _MSMVSampling.apply(*mlvl_feats, sampling_locations, scale_weights)

@@ -1,0 +1,266 @@
+"""GPU parity tests: the HIP path (through the C ABI, via opus_amd.csrc.wrapper) against
+the golden fixtures and the CPU oracle.  Bars: forward 1e-5 relative, gradients 1e-4
+relative (helpers.FWD_RTOL / GRAD_RTOL), relative to each tensor's max magnitude."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (FWD_RTOL, GRAD_RTOL, REAL_LEVELS, TINY_LEVELS, assert_close,
+                     check_dfeat_digest, golden_feats, load_golden, random_case)
+
+pytestmark = pytest.mark.gpu
+
+DENSE = ["g1_tiny4", "g2_edges", "g2_p32", "g3_tiny5"]
+REAL = ["g4_real_p2", "g4_real_p4"]
+ALGOS = ["atomic", "owner"]
+
+
+@pytest.fixture(scope="module")
+def wr():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from opus_amd.csrc import wrapper
+    assert wrapper.MSMV_CUDA, "libopus_msmv.so must be loaded on the GPU box"
+    return wrapper
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_hip(wr, feats, loc, w, grad_out=None, algo=None, flags=0):
+    f = [dev(x) for x in feats]
+    l, ww = dev(loc), dev(w)
+    out = wr.msmv_forward(f, l, ww, flags=flags)
+    if grad_out is None:
+        return out.cpu().numpy()
+    dfeats, dloc, dw = wr.msmv_backward(dev(grad_out), f, l, ww, algo=algo)
+    torch.cuda.synchronize()
+    return (out.cpu().numpy(), [d.cpu().numpy() for d in dfeats], dloc.cpu().numpy(), dw.cpu().numpy())
+
+
+def supports_owner(feats):
+    return feats[0].shape[-1] == 64 and len(feats) in (4, 5)
+
+
+# ---------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("name", DENSE + REAL)
+def test_forward_matches_golden(wr, name):
+    g = load_golden(name)
+    out = run_hip(wr, golden_feats(g), g["loc"], g["w"])
+    assert_close(out, g["out"], FWD_RTOL, f"{name} forward")
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_backward_matches_golden(wr, name):
+    g = load_golden(name)
+    feats = golden_feats(g)
+    _, dfeats, dloc, dw = run_hip(wr, feats, g["loc"], g["w"], g["grad_out"], algo="auto")
+    for i, d in enumerate(dfeats):
+        assert_close(d, g[f"dfeat{i}"], GRAD_RTOL, f"{name} dfeat{i}")
+    assert_close(dloc[..., :2], g["dloc_xy"], GRAD_RTOL, f"{name} dloc xy")
+    assert_close(dw, g["dw"], GRAD_RTOL, f"{name} dw")
+    assert (dloc[..., 2] == 0).all()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("name", REAL)
+def test_backward_matches_golden_real_size(wr, name, algo):
+    g = load_golden(name)
+    feats = golden_feats(g)
+    _, dfeats, dloc, dw = run_hip(wr, feats, g["loc"], g["w"], g["grad_out"], algo=algo)
+    check_dfeat_digest(g, dfeats)
+    assert_close(dloc[..., :2], g["dloc_xy"], GRAD_RTOL, f"{name} dloc xy")
+    assert_close(dw, g["dw"], GRAD_RTOL, f"{name} dw")
+    assert (dloc[..., 2] == 0).all()
+
+
+# ---------------------------------------------------------------- oracle, seeded random
+CASES = [
+    # levels, B, N, C, Q, P, oob
+    (REAL_LEVELS, 3, 6, 64, 50, 1, 0.25),
+    (REAL_LEVELS, 3, 6, 64, 37, 2, 0.25),
+    (REAL_LEVELS, 2, 6, 64, 33, 3, 0.25),
+    (REAL_LEVELS, 2, 6, 64, 21, 4, 0.25),
+    (REAL_LEVELS, 1, 6, 64, 9, 8, 0.5),
+    (REAL_LEVELS + [(4, 11)], 2, 6, 64, 19, 2, 0.25),
+    (REAL_LEVELS + [(4, 11)], 2, 6, 64, 11, 4, 0.25),
+    (TINY_LEVELS, 2, 6, 8, 13, 3, 0.25),
+    (TINY_LEVELS, 2, 3, 96, 7, 2, 0.25),
+    (TINY_LEVELS[:3], 2, 2, 64, 7, 2, 0.25),
+    (TINY_LEVELS[:1], 1, 1, 5, 4, 1, 0.25),
+    (REAL_LEVELS + TINY_LEVELS, 1, 2, 16, 6, 2, 0.25),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"L{len(c[0])}B{c[1]}N{c[2]}C{c[3]}Q{c[4]}P{c[5]}")
+def test_forward_backward_match_oracle(wr, oracle, case):
+    levels, B, N, C, Q, P, oob = case
+    feats, loc, w, grad_out = random_case(hash(case[1:]) % 10000, levels, B, N, C, Q, P, oob)
+    ref_out = oracle.forward(feats, loc, w)
+    ref_df, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
+    algos = ALGOS if supports_owner(feats) else ["atomic"]
+    for algo in algos:
+        out, dfeats, dloc, dw = run_hip(wr, feats, loc, w, grad_out, algo=algo)
+        assert_close(out, ref_out, FWD_RTOL, f"forward [{algo}]")
+        for i, d in enumerate(dfeats):
+            assert_close(d, ref_df[i], GRAD_RTOL, f"dfeat{i} [{algo}]")
+        assert_close(dloc, ref_dloc, GRAD_RTOL, f"dloc [{algo}]")
+        assert_close(dw, ref_dw, GRAD_RTOL, f"dw [{algo}]")
+    # the any-shape forward kernel on the same input
+    out_generic = run_hip(wr, feats, loc, w, flags=1)
+    assert_close(out_generic, ref_out, FWD_RTOL, "forward [generic kernel]")
+
+
+def test_out_of_range_view_and_nan_location(wr, oracle):
+    feats, loc, w, grad_out = random_case(5, REAL_LEVELS, B=1, N=6, C=64, Q=8, P=2, oob_frac=0)
+    loc[0, 0, 0, 2] = 1.3
+    loc[0, 1, 1, 2] = -0.2
+    loc[0, 2, 0, 0] = np.nan
+    loc[0, 3, 1, 1] = np.inf
+    ref_out = oracle.forward(feats, loc, w)
+    for algo in ALGOS:
+        out, dfeats, dloc, dw = run_hip(wr, feats, loc, w, grad_out, algo=algo)
+        assert_close(out, ref_out, FWD_RTOL, "forward")
+        assert (out[0, 0, :, 0] == 0).all() and (out[0, 2, :, 0] == 0).all()
+        assert (dloc[0, 0, 0] == 0).all() and (dw[0, 2, 0] == 0).all()
+        assert all(np.isfinite(d).all() for d in dfeats)
+
+
+# ---------------------------------------------------------------- API behaviour
+def test_autograd_functions_and_dispatch(wr, oracle):
+    feats, loc, w, grad_out = random_case(21, REAL_LEVELS, B=2, N=6, C=64, Q=10, P=2)
+    f = [dev(x).requires_grad_(True) for x in feats]
+    l, ww = dev(loc).requires_grad_(True), dev(w).requires_grad_(True)
+    out = wr.msmv_sampling(f, l, ww)
+    assert out.shape == (2, 10, 64, 2) and out.is_contiguous()
+    # a non-contiguous upstream gradient is made contiguous (reference wrapper.py:56)
+    g = dev(grad_out.transpose(0, 2, 1, 3).copy()).permute(0, 2, 1, 3)
+    assert not g.is_contiguous()
+    out.backward(g)
+    ref_df, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
+    for i in range(4):
+        assert_close(f[i].grad.cpu().numpy(), ref_df[i], GRAD_RTOL, f"dfeat{i}")
+    assert_close(l.grad.cpu().numpy(), ref_dloc, GRAD_RTOL, "dloc")
+    assert_close(ww.grad.cpu().numpy(), ref_dw, GRAD_RTOL, "dw")
+    out2 = wr.MSMVSamplingC2345.apply(*[x.detach() for x in f], l.detach(), ww.detach())
+    assert torch.equal(out2, out.detach())
+    with pytest.raises(TypeError):
+        wr.MSMVSamplingC23456.apply(*[x.detach() for x in f], l.detach(), ww.detach())
+
+
+def test_precondition_errors(wr):
+    feats, loc, w, _ = random_case(3, TINY_LEVELS, B=1, N=6, C=8, Q=4, P=2)
+    f = [dev(x) for x in feats]
+    l, ww = dev(loc), dev(w)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        wr.msmv_sampling([f[0].transpose(2, 3)] + f[1:], l, ww)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        wr.msmv_sampling(f, l.cpu(), ww)
+    with pytest.raises(RuntimeError, match="float32"):
+        wr.msmv_sampling(f, l.double(), ww)
+    # P = 33 exceeds MAX_POINT (msmv_sampling.cpp:125)
+    feats, loc, w, _ = random_case(3, TINY_LEVELS, B=1, N=6, C=8, Q=2, P=33)
+    with pytest.raises(RuntimeError, match="num_point exceed limits"):
+        wr.msmv_sampling([dev(x) for x in feats], dev(loc), dev(w))
+
+
+def test_c_abi_error_codes(wr):
+    import ctypes
+    from opus_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    hw = _lib.int_array([4, 4])
+    ptrs = _lib.ptr_array([0])
+    assert lib.opus_msmv_forward(0, ptrs, hw, null, null, 1, 8, 6, 1, 1, null, null) == -1
+    assert lib.opus_msmv_forward(1, ptrs, hw, null, null, 1, 8, 6, 1, 33, null, null) == -2
+    assert lib.opus_msmv_forward(1, ptrs, hw, null, null, 1, 0, 6, 1, 1, null, null) == -3
+    assert lib.opus_msmv_forward(1, ptrs, hw, null, null, 1, 8, 6, 1, 1, null, null) == -4
+    assert lib.opus_msmv_forward(1, ptrs, hw, null, null, 1 << 20, 64, 6, 1 << 10, 32, null, null) == -5
+    assert lib.opus_msmv_forward(1, ptrs, hw, null, null, 0, 8, 6, 5, 1, null, null) == 0   # empty batch
+
+
+def test_empty_query_set(wr):
+    feats, loc, w, grad_out = random_case(4, REAL_LEVELS, B=1, N=6, C=64, Q=0, P=2)
+    for algo in ALGOS:
+        out, dfeats, dloc, dw = run_hip(wr, feats, loc, w, grad_out, algo=algo)
+        assert out.shape == (1, 0, 64, 2)
+        assert all((d == 0).all() for d in dfeats)
+
+
+def test_non_default_stream_and_accumulate(wr, oracle):
+    feats, loc, w, grad_out = random_case(9, REAL_LEVELS, B=1, N=6, C=64, Q=16, P=4)
+    f = [dev(x) for x in feats]
+    l, ww, g = dev(loc), dev(w), dev(grad_out)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out = wr.msmv_forward(f, l, ww)
+        dfeats, dloc, dw = wr.msmv_backward(g, f, l, ww, algo="owner")
+        # accumulate a second backward onto the first: d feats double
+        wr.msmv_backward(g, f, l, ww, dfeats=dfeats)
+    s.synchronize()
+    ref_df, _, _ = oracle.backward(grad_out, feats, loc, w)
+    assert_close(out.cpu().numpy(), oracle.forward(feats, loc, w), FWD_RTOL, "forward on side stream")
+    for i, d in enumerate(dfeats):
+        assert_close(d.cpu().numpy(), 2 * ref_df[i], GRAD_RTOL, f"accumulated dfeat{i}")
+
+
+# ---------------------------------------------------------------- full-size properties
+def _device_case(B, Q, P, seed, levels=REAL_LEVELS, N=6, C=64):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    feats = [torch.randn((B, N, h, w, C), generator=gen, device="cuda") for h, w in levels]
+    xy = torch.rand((B, Q, P, 2), generator=gen, device="cuda") * 1.2 - 0.1
+    view = torch.randint(0, N, (B, Q, P, 1), generator=gen, device="cuda").float() / (N - 1)
+    loc = torch.cat([xy, view], -1).contiguous()
+    w = torch.softmax(torch.randn((B, Q, P, len(levels)), generator=gen, device="cuda"), -1)
+    g = torch.randn((B, Q, C, P), generator=gen, device="cuda")
+    return feats, loc, w, g
+
+
+@pytest.mark.parametrize("shape", [(32, 4800, 2), (32, 600, 4)], ids=["OPUS-L", "OPUS-T"])
+def test_full_size_adjoint_identities(wr, shape):
+    """At the benchmark sizes the oracle is too slow; use what linearity gives for free:
+    the op is linear in feats and in weights, so <g, F(feats, w)> = <dfeats, feats> = <dw, w>,
+    and the two backward algorithms must agree with each other."""
+    B, Q, P = shape
+    feats, loc, w, g = _device_case(B, Q, P, seed=1234)
+    out = wr.msmv_forward(feats, loc, w)
+    lhs = (out.double() * g.double()).sum().item()
+    scale = (out.double().abs() * g.double().abs()).sum().item()
+    res = {}
+    for algo in ALGOS:
+        dfeats, dloc, dw = wr.msmv_backward(g, feats, loc, w, algo=algo)
+        via_feats = sum((d.double() * f.double()).sum().item() for d, f in zip(dfeats, feats))
+        via_w = (dw.double() * w.double()).sum().item()
+        assert abs(via_feats - lhs) <= 1e-5 * scale, (algo, via_feats, lhs)
+        assert abs(via_w - lhs) <= 1e-5 * scale, (algo, via_w, lhs)
+        assert (dloc[..., 2] == 0).all()
+        res[algo] = (dfeats, dloc, dw)
+    for i in range(len(feats)):
+        a, o = res["atomic"][0][i], res["owner"][0][i]
+        assert (a - o).abs().max().item() <= GRAD_RTOL * a.abs().max().item(), f"dfeat{i} algos disagree"
+    for k in (1, 2):
+        a, o = res["atomic"][k], res["owner"][k]
+        assert (a - o).abs().max().item() <= GRAD_RTOL * a.abs().max().item()
+
+
+def test_full_size_forward_generic_vs_fast_and_subset_oracle(wr, oracle):
+    B, Q, P = 32, 4800, 2
+    feats, loc, w, g = _device_case(B, Q, P, seed=77)
+    fast = wr.msmv_forward(feats, loc, w)
+    generic = wr.msmv_forward(feats, loc, w, flags=1)
+    assert (fast - generic).abs().max().item() <= FWD_RTOL * fast.abs().max().item()
+    # the oracle on the last batch slab only (exercises the largest offsets)
+    sl = slice(B - 1, B)
+    ref = oracle.forward([f[sl].cpu().numpy() for f in feats], loc[sl].cpu().numpy(), w[sl].cpu().numpy())
+    assert_close(fast[sl].cpu().numpy(), ref, FWD_RTOL, "last slab vs oracle")
+    # backward of the last slab against the oracle, both algorithms
+    ref_df, ref_dloc, ref_dw = oracle.backward(
+        g[sl].cpu().numpy(), [f[sl].cpu().numpy() for f in feats],
+        loc[sl].cpu().numpy(), w[sl].cpu().numpy())
+    for algo in ALGOS:
+        dfeats, dloc, dw = wr.msmv_backward(g, feats, loc, w, algo=algo)
+        for i, d in enumerate(dfeats):
+            assert_close(d[sl].cpu().numpy(), ref_df[i], GRAD_RTOL, f"dfeat{i} last slab [{algo}]")
+        assert_close(dloc[sl].cpu().numpy(), ref_dloc, GRAD_RTOL, f"dloc last slab [{algo}]")
+        assert_close(dw[sl].cpu().numpy(), ref_dw, GRAD_RTOL, f"dw last slab [{algo}]")
