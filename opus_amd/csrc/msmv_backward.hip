@@ -99,89 +99,190 @@ struct BinEntry {       // 16 bytes, one aligned load
     int pad;
 };
 
-// workspace layout: [ counts: B*N ints ][ cursors: B*N ints ][ pad to 256 B ][ entries: npts * 16 B ]
+constexpr int BIN_YB = 16;               // y-bands per (batch, view)
+constexpr int BIN_XB = 8;                // x-bands per y-band
+constexpr int BIN_PER_VIEW = BIN_YB * BIN_XB;
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_MAX_KEYS = 2048;       // N * BIN_PER_VIEW must not exceed this
+
+// workspace layout: [ offsets: B * (keys+1) ints, padded to 256 B ][ entries: npts * 16 B ]
+// entries of batch b occupy [b*QP, b*QP + offsets[b][keys]), sorted by
+// key = (view*BIN_YB + yband)*BIN_XB + xband; offsets[b][k] is the exclusive prefix of the
+// key counts of batch b.
 struct OwnerWs {
-    int *counts;
-    int *cursors;
+    int *offsets;
     BinEntry *entries;
+    int keys;             // N * BIN_PER_VIEW
 };
 
 __host__ __device__ inline size_t owner_ws_header_bytes(int B, int N)
 {
-    const size_t h = (size_t)B * N * 2 * sizeof(int);
+    const size_t h = (size_t)B * (N * BIN_PER_VIEW + 1) * sizeof(int);
     return (h + 255) & ~(size_t)255;
 }
 
-// FILL == false: count points per (batch, view).  FILL == true: write each point's entry at
-// b*QP + (points of b in lower views) + its slot among the points of its own (b, view).
-template <bool FILL>
-__global__ void __launch_bounds__(256)
-msmv_bin_points(const MsmvArgs a, OwnerWs ws)
+// Band of a normalised coordinate: monotone in the coordinate, so a pixel interval maps to
+// a band interval.  Coordinates outside [0,1) go to the first / last band; NaN goes to 0.
+template <int NB>
+__device__ __forceinline__ int msmv_band_of(float y)
 {
-    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int key = -1;
-    float x = 0.f, y = 0.f;
-    int b = 0, view = -1;
-    if (pt < a.npts) {
-        x = a.loc[(size_t)pt * 3];
-        y = a.loc[(size_t)pt * 3 + 1];
-        view = msmv_view_of(a.loc[(size_t)pt * 3 + 2], a.N);
-        b = msmv_batch_of(pt, a);
-        if (view >= 0)
-            key = b * a.N + view;
+    const float f = y * (float)NB;
+    return f >= (float)(NB - 1) ? NB - 1 : (f > 0.f ? (int)f : 0);
+}
+
+// Conservative band interval of the locations whose 2x2 footprint can reach pixels
+// lo..hi (inclusive) of an axis with `size` pixels: floor(v*(size-1)) is lo-1..hi, i.e.
+// v*(size-1) in [lo-1, hi+1).  The 1e-3 margin (in bands) dwarfs the rounding of either
+// product.  size == 1 maps every location to pixel 0.
+template <int NB>
+__device__ __forceinline__ void msmv_band_range(int lo, int hi, int size, int &b_lo, int &b_hi)
+{
+    b_lo = 0;
+    b_hi = NB - 1;
+    if (size > 1) {
+        const float flo = (float)NB * (float)(lo - 1) / (float)(size - 1) - 1e-3f;
+        const float fhi = (float)NB * (float)(hi + 1) / (float)(size - 1) + 1e-3f;
+        b_lo = flo <= 0.f ? 0 : min((int)flo, NB - 1);
+        b_hi = fhi >= (float)(NB - 1) ? NB - 1 : max((int)fhi, 0);
     }
-    // group the wave's lanes by key; one atomic per distinct key per wave
-    unsigned long long todo = __ballot(key >= 0);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __builtin_amdgcn_readlane(key, leader);
-        const unsigned long long same = __ballot(key == k);
-        const int n = __popcll(same);
-        if (!FILL) {
-            if (lane == leader)
-                atomicAdd(ws.counts + k, n);
-        } else {
-            int slot0 = 0;
-            if (lane == leader)
-                slot0 = atomicAdd(ws.cursors + k, n);
-            slot0 = __builtin_amdgcn_readlane(slot0, leader);
-            if (key == k) {
-                const int rank = __popcll(same & ((1ull << lane) - 1ull));
-                int lower = 0;
-                for (int v = 0; v < view; ++v)
-                    lower += ws.counts[b * a.N + v];
-                BinEntry e;
-                e.pt = pt; e.x = x; e.y = y; e.pad = 0;
-                ws.entries[(size_t)b * a.qp + lower + slot0 + rank] = e;
-            }
+}
+
+// One workgroup per batch slab: LDS histogram over (view, yband, xband), exclusive scan,
+// then a second sweep that writes each point's entry into its key's segment.
+__global__ void __launch_bounds__(BIN_THREADS)
+msmv_bin_sort(const MsmvArgs a, OwnerWs ws)
+{
+    __shared__ int hist[BIN_MAX_KEYS];
+    __shared__ int scan[2][BIN_MAX_KEYS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int keys = ws.keys;
+    const size_t pt0 = (size_t)b * a.qp;
+
+    for (int k = tid; k < keys; k += BIN_THREADS)
+        hist[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < a.qp; i += BIN_THREADS) {
+        const float *lp = a.loc + (pt0 + i) * 3;
+        const int view = msmv_view_of(lp[2], a.N);
+        if (view >= 0)
+            atomicAdd(&hist[(view * BIN_YB + msmv_band_of<BIN_YB>(lp[1])) * BIN_XB + msmv_band_of<BIN_XB>(lp[0])], 1);
+    }
+    __syncthreads();
+    // inclusive Hillis-Steele scan of hist (keys <= 2048: at most 11 steps)
+    int cur = 0;
+    for (int k = tid; k < keys; k += BIN_THREADS)
+        scan[0][k] = hist[k];
+    __syncthreads();
+    for (int d = 1; d < keys; d <<= 1) {
+        for (int k = tid; k < keys; k += BIN_THREADS)
+            scan[cur ^ 1][k] = scan[cur][k] + (k >= d ? scan[cur][k - d] : 0);
+        cur ^= 1;
+        __syncthreads();
+    }
+    int *off = ws.offsets + (size_t)b * (keys + 1);
+    for (int k = tid; k < keys; k += BIN_THREADS) {
+        const int excl = scan[cur][k] - hist[k];
+        off[k] = excl;
+        hist[k] = excl;                    // becomes the fill cursor
+        if (k == keys - 1)
+            off[keys] = scan[cur][k];
+    }
+    __syncthreads();
+    BinEntry *dst = ws.entries + pt0;
+    for (int i = tid; i < a.qp; i += BIN_THREADS) {
+        const float *lp = a.loc + (pt0 + i) * 3;
+        const float x = lp[0], y = lp[1];
+        const int view = msmv_view_of(lp[2], a.N);
+        if (view >= 0) {
+            const int slot = atomicAdd(&hist[(view * BIN_YB + msmv_band_of<BIN_YB>(y)) * BIN_XB + msmv_band_of<BIN_XB>(x)], 1);
+            int4 e;
+            e.x = (int)(pt0 + i); e.y = __float_as_int(x); e.z = __float_as_int(y); e.w = 0;
+            *reinterpret_cast<int4 *>(dst + slot) = e;
         }
-        todo &= ~same;
     }
 }
 
 // ======================================================================================
 // owner algorithm: d feat tiles
 // ======================================================================================
-constexpr int TILE_PIX = 176;            // pixels per tile: 176 * 256 B = 44 KiB of LDS, 3 workgroups per CU
-constexpr int OWN_THREADS = 256;
+// LDS float atomics (ds_add_f32) cost ~190 LDS cycles per wave instruction on gfx950, so
+// no two waves ever share a pixel: each WAVE owns a run of SUB_PIX consecutive pixels of one
+// (batch, view, level) slab, keeps it in its private slice of LDS and updates it with plain
+// ds_read_b128 / ds_write_b128.  A hit (a point with at least one corner in the run) is
+// handled by the whole wave at once: row r of 16 lanes takes corner r, each lane 4 channels.
+constexpr int SUB_PIX = 22;              // pixels per wave: 22 * 256 B = 5.5 KiB of LDS
+constexpr int OWN_WAVES = 8;
+constexpr int OWN_THREADS = OWN_WAVES * 64;
+constexpr int TILE_PIX = SUB_PIX * OWN_WAVES;   // 176 pixels = 44 KiB per workgroup, 3 workgroups per CU
+constexpr int OWN_BATCH = 4;             // hits whose gradient vectors are in flight together
 
 struct OwnerGeom {
-    int tiles_per_level[MSMV_MAX_LEVELS];   // tiles per (batch, view) slab of the level
+    int tiles_per_level[MSMV_MAX_LEVELS];   // workgroups per (batch, view) slab of the level
     int tiles_per_b;                         // N * sum over levels
-    int p_magic_valid;                       // unused placeholder for alignment
 };
 
+// Gradient vector of one point for this lane's 4 channels (4*l16 .. 4*l16+3).  grad_out is
+// [B,Q,C,P]: for P in {1,2,4} the lane's 4*P floats are contiguous and fetched with 16-byte
+// loads (the P-strided dword form runs at about one lane per cycle).
+template <int PT>
+__device__ __forceinline__ void msmv_load_grad(const MsmvArgs &a, int pt, int l16, float4 (&v)[PT == 0 ? 1 : PT])
+{
+    if constexpr (PT == 0) {
+        const int bq = pt / a.P, p = pt - bq * a.P;
+        const float *gp = a.gout + ((size_t)bq * 64 + l16 * 4) * a.P + p;
+        v[0] = make_float4(gp[0], gp[(size_t)a.P], gp[(size_t)a.P * 2], gp[(size_t)a.P * 3]);
+    } else {
+        const float4 *gp = reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt / PT) * 64 + l16 * 4) * PT);
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+            v[k] = gp[k];
+    }
+}
+
+template <int PT>
+__device__ __forceinline__ float4 msmv_select_grad(const float4 (&v)[PT == 0 ? 1 : PT], int pt)
+{
+    // component-wise selects on named values: selecting between whole vectors by a scalar
+    // makes hipcc spill the array to scratch and index it
+    if constexpr (PT == 0 || PT == 1) {
+        return v[0];
+    } else if constexpr (PT == 2) {
+        const bool odd = pt & 1;
+        const float4 A = v[0], B = v[1];
+        float4 r;
+        r.x = odd ? A.y : A.x;
+        r.y = odd ? A.w : A.z;
+        r.z = odd ? B.y : B.x;
+        r.w = odd ? B.w : B.z;
+        return r;
+    } else {
+        const bool p1 = pt & 1, p2 = pt & 2;
+        float4 r;
+#define MSMV_PICK(V) (p2 ? (p1 ? (V).w : (V).z) : (p1 ? (V).y : (V).x))
+        const float4 A = v[0], B = v[1], C = v[2], D = v[3];
+        r.x = MSMV_PICK(A);
+        r.y = MSMV_PICK(B);
+        r.z = MSMV_PICK(C);
+        r.w = MSMV_PICK(D);
+#undef MSMV_PICK
+        return r;
+    }
+}
+
+template <int PT>
 __global__ void __launch_bounds__(OWN_THREADS)
 msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 {
-    __shared__ float tile[TILE_PIX * 64];
+    constexpr int BATCH = PT == 4 ? 2 : OWN_BATCH;
+    __shared__ float4 tile_all[OWN_WAVES][SUB_PIX * 16];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 4, l16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *tile = tile_all[wave];
 
-    // ---- which tile: logical order [b][level, coarse first][view][tile]
+    // ---- which run of pixels: logical order [b][level, coarse first][view][tile][wave]
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
     const int b = id / geo.tiles_per_b;
     id -= b * geo.tiles_per_b;
@@ -196,93 +297,114 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     const int tile_idx = id - view * geo.tiles_per_level[l];
     const int H = a.lvl[l].H, W = a.lvl[l].W;
     const int S = H * W;
-    const int s0 = tile_idx * TILE_PIX;                 // first pixel of the run
-    const int npix = min(TILE_PIX, S - s0);
+    const int s0 = tile_idx * TILE_PIX + wave * SUB_PIX;     // first pixel of this wave's run
+    const int npix = min(SUB_PIX, S - s0);
+    if (npix <= 0)
+        return;                                              // wave-uniform; no barriers below
 
-    // ---- clear the tile
-    {
-        float4 *t4 = reinterpret_cast<float4 *>(tile);
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < npix * 16; i += OWN_THREADS)
-            t4[i] = z;
-    }
-    __syncthreads();
+    for (int i = lane; i < npix * 16; i += 64)
+        tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- scan this (batch, view)'s bin
-    int lower = 0;
-    for (int v = 0; v < view; ++v)
-        lower += ws.counts[b * a.N + v];
-    const int n = ws.counts[b * a.N + view];
-    const BinEntry *list = ws.entries + (size_t)b * a.qp + lower;
+    // ---- the bins that can reach this run
+    const int r0 = s0 / W, r1 = (s0 + npix - 1) / W;
+    int yb_lo, yb_hi, xb_lo = 0, xb_hi = BIN_XB - 1;
+    msmv_band_range<BIN_YB>(r0, r1, H, yb_lo, yb_hi);
+    if (r0 == r1)
+        msmv_band_range<BIN_XB>(s0 - r0 * W, s0 + npix - 1 - r0 * W, W, xb_lo, xb_hi);
+    const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
+    const int *off = ws.offsets + (size_t)b * (ws.keys + 1) + view * BIN_PER_VIEW;
+    const int4 *list = reinterpret_cast<const int4 *>(ws.entries + (size_t)b * a.qp);
+    // with every x-band wanted the y-bands' segments are adjacent: one segment in all
+    const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;
 
-    for (int i0 = wave * 64; i0 < n; i0 += (OWN_THREADS / 64) * 64) {
-        const int i = i0 + lane;
-        const bool valid = i < n;
-        BinEntry e;
-        if (valid) {
-            const int4 raw = *reinterpret_cast<const int4 *>(list + i);
-            e.pt = raw.x; e.x = __int_as_float(raw.y); e.y = __int_as_float(raw.z);
-        } else {
-            e.pt = 0; e.x = 0.f; e.y = 0.f;
-        }
-        const MsmvTap t = msmv_make_tap(e.x, e.y, H, W, valid);
-        // corners that fall into this tile's run of pixels
-        const bool in1 = t.c1 && (unsigned)(t.o1 - s0) < (unsigned)npix;
-        const bool in2 = t.c2 && (unsigned)(t.o2 - s0) < (unsigned)npix;
-        const bool in3 = t.c3 && (unsigned)(t.o3 - s0) < (unsigned)npix;
-        const bool in4 = t.c4 && (unsigned)(t.o4 - s0) < (unsigned)npix;
-        const float cw1 = in1 ? t.w1 : 0.f, cw2 = in2 ? t.w2 : 0.f;
-        const float cw3 = in3 ? t.w3 : 0.f, cw4 = in4 ? t.w4 : 0.f;
-        const int co1 = in1 ? (t.o1 - s0) * 64 : -1, co2 = in2 ? (t.o2 - s0) * 64 : -1;
-        const int co3 = in3 ? (t.o3 - s0) * 64 : -1, co4 = in4 ? (t.o4 - s0) * 64 : -1;
-        const int bq = e.pt / a.P, p = e.pt - bq * a.P;
-        const int goff = bq * 64 * a.P + p;            // < 2^31: host checks B*Q*C*P
-        const int woff = e.pt * a.L + l;
+#ifdef MSMV_ABL_NOSCAN
+    if (false)
+#endif
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int k_lo = all_x ? yb_lo * BIN_XB : (yb_lo + sg) * BIN_XB + xb_lo;
+        const int k_hi = all_x ? (yb_hi + 1) * BIN_XB : (yb_lo + sg) * BIN_XB + xb_hi + 1;
+        const int seg_begin = off[k_lo], seg_end = off[k_hi];
 
-        unsigned long long hits = __ballot(in1 || in2 || in3 || in4);
-        while (hits) {
-            // up to two hits per round so that both gradient loads are in flight together
-            const int j0 = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            const bool two = hits != 0;
-            const int j1 = two ? __ffsll((long long)hits) - 1 : j0;
-            if (two)
-                hits &= hits - 1;
+        for (int i0 = seg_begin; i0 < seg_end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < seg_end;
+            const int4 cur = list[valid ? i : seg_end - 1];
+            const int pt = cur.x;
+            const MsmvTap t = msmv_make_tap(__int_as_float(cur.y), __int_as_float(cur.z), H, W, valid);
+            // corners that fall into this wave's run of pixels
+            const bool in1 = t.c1 && (unsigned)(t.o1 - s0) < (unsigned)npix;
+            const bool in2 = t.c2 && (unsigned)(t.o2 - s0) < (unsigned)npix;
+            const bool in3 = t.c3 && (unsigned)(t.o3 - s0) < (unsigned)npix;
+            const bool in4 = t.c4 && (unsigned)(t.o4 - s0) < (unsigned)npix;
+            const bool hit = in1 || in2 || in3 || in4;
+            float wl = 0.f;
+            if (hit)
+                wl = a.w[(size_t)pt * a.L + l];
+            // float4 index of the corner's pixel inside the run, or -1
+            const int co1 = in1 ? (t.o1 - s0) * 16 : -1, co2 = in2 ? (t.o2 - s0) * 16 : -1;
+            const int co3 = in3 ? (t.o3 - s0) * 16 : -1, co4 = in4 ? (t.o4 - s0) * 16 : -1;
+            const float cw1 = t.w1 * wl, cw2 = t.w2 * wl, cw3 = t.w3 * wl, cw4 = t.w4 * wl;
 
-            const int goff0 = __builtin_amdgcn_readlane(goff, j0), goff1 = __builtin_amdgcn_readlane(goff, j1);
-            const int woff0 = __builtin_amdgcn_readlane(woff, j0), woff1 = __builtin_amdgcn_readlane(woff, j1);
-            const float g0 = a.gout[(size_t)goff0 + (size_t)lane * a.P] * a.w[woff0];
-            const float g1 = a.gout[(size_t)goff1 + (size_t)lane * a.P] * a.w[woff1];
-
-#define MSMV_OWNER_ADD(J, G)                                                                   \
-            {                                                                                  \
-                const int o1 = __builtin_amdgcn_readlane(co1, J), o2 = __builtin_amdgcn_readlane(co2, J); \
-                const int o3 = __builtin_amdgcn_readlane(co3, J), o4 = __builtin_amdgcn_readlane(co4, J); \
-                const float k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw1), J)); \
-                const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw2), J)); \
-                const float k3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw3), J)); \
-                const float k4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw4), J)); \
-                if (o1 >= 0) unsafeAtomicAdd(&tile[o1 + lane], k1 * (G));                       \
-                if (o2 >= 0) unsafeAtomicAdd(&tile[o2 + lane], k2 * (G));                       \
-                if (o3 >= 0) unsafeAtomicAdd(&tile[o3 + lane], k3 * (G));                       \
-                if (o4 >= 0) unsafeAtomicAdd(&tile[o4 + lane], k4 * (G));                       \
+            unsigned long long hits = __ballot(hit);
+#ifdef MSMV_ABL_NOHITS
+            asm volatile("" ::"v"(co1), "v"(co2), "v"(co3), "v"(co4), "v"(cw1), "v"(cw2), "v"(cw3), "v"(cw4));
+            hits = 0;
+#endif
+            while (hits) {
+                int j[BATCH], hpt[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    j[u] = hits ? __ffsll((long long)hits) - 1 : -1;
+                    hits &= hits - 1;                      // 0 stays 0
+                }
+                float4 gv[BATCH][PT == 0 ? 1 : PT];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    // an empty slot re-reads the first hit's vector: no branch around the loads
+                    hpt[u] = __builtin_amdgcn_readlane(pt, j[u] >= 0 ? j[u] : j[0]);
+                    msmv_load_grad<PT>(a, hpt[u], l16, gv[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    if (j[u] >= 0) {
+                        const int J = j[u];
+                        const float4 gu = msmv_select_grad<PT>(gv[u], hpt[u]);
+                        const int o1 = __builtin_amdgcn_readlane(co1, J), o2 = __builtin_amdgcn_readlane(co2, J);
+                        const int o3 = __builtin_amdgcn_readlane(co3, J), o4 = __builtin_amdgcn_readlane(co4, J);
+                        const float k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw1), J));
+                        const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw2), J));
+                        const float k3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw3), J));
+                        const float k4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw4), J));
+                        // row r of the wave takes corner r; the four corners are distinct pixels
+                        const int o = row == 0 ? o1 : row == 1 ? o2 : row == 2 ? o3 : o4;
+                        const float k = row == 0 ? k1 : row == 1 ? k2 : row == 2 ? k3 : k4;
+#ifdef MSMV_ABL_NORMW
+                        asm volatile("" ::"v"(k), "v"(o), "v"(gu.x), "v"(gu.y), "v"(gu.z), "v"(gu.w));
+                        if (false) {
+#else
+                        if (o >= 0) {
+#endif
+                            float4 acc = tile[o + l16];
+                            acc.x += k * gu.x;
+                            acc.y += k * gu.y;
+                            acc.z += k * gu.z;
+                            acc.w += k * gu.w;
+                            tile[o + l16] = acc;
+                        }
+                    }
+                }
             }
-            MSMV_OWNER_ADD(j0, g0)
-            if (two)
-                MSMV_OWNER_ADD(j1, g1)
-#undef MSMV_OWNER_ADD
         }
     }
-    __syncthreads();
 
-    // ---- write the run once
-    {
-        const float4 *t4 = reinterpret_cast<const float4 *>(tile);
-        float4 *dst = reinterpret_cast<float4 *>(
-            a.lvl[l].dfeat + (((size_t)b * a.N + view) * (size_t)S + s0) * 64);
-        for (int i = tid; i < npix * 16; i += OWN_THREADS)
-            dst[i] = t4[i];
-    }
+    // ---- write the run once (LDS operations of one wave complete in order)
+    float4 *dst = reinterpret_cast<float4 *>(
+        a.lvl[l].dfeat + (((size_t)b * a.N + view) * (size_t)S + s0) * 64);
+#ifdef MSMV_ABL_NOSTORE
+    if (npix < 0)
+#endif
+    for (int i = lane; i < npix * 16; i += 64)
+        dst[i] = tile[i];
 }
 
 // ======================================================================================
@@ -444,7 +566,7 @@ hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool ac
 
 bool msmv_backward_owner_supported(const MsmvArgs &a)
 {
-    return a.C == 64 && (a.L == 4 || a.L == 5);
+    return a.C == 64 && (a.L == 4 || a.L == 5) && a.N * BIN_PER_VIEW <= BIN_MAX_KEYS;
 }
 
 size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
@@ -455,20 +577,14 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
 hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s)
 {
     OwnerWs ws;
-    ws.counts = reinterpret_cast<int *>(workspace);
-    ws.cursors = ws.counts + (size_t)a.B * a.N;
+    ws.offsets = reinterpret_cast<int *>(workspace);
     ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N));
+    ws.keys = a.N * BIN_PER_VIEW;
 
-    hipError_t e = hipMemsetAsync(workspace, 0, owner_ws_header_bytes(a.B, a.N), s);
-    if (e != hipSuccess)
+    hipError_t e;
+    hipLaunchKernelGGL(msmv_bin_sort, dim3(a.B), dim3(BIN_THREADS), 0, s, a, ws);
+    if ((e = hipGetLastError()) != hipSuccess)
         return e;
-    if (a.npts > 0) {
-        const int nblk = (a.npts + 255) / 256;
-        hipLaunchKernelGGL((msmv_bin_points<false>), dim3(nblk), dim3(256), 0, s, a, ws);
-        hipLaunchKernelGGL((msmv_bin_points<true>), dim3(nblk), dim3(256), 0, s, a, ws);
-        if ((e = hipGetLastError()) != hipSuccess)
-            return e;
-    }
 
     OwnerGeom geo = {};
     int per_view = 0;
@@ -478,11 +594,15 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     }
     geo.tiles_per_b = per_view * a.N;
     const long long ntiles = (long long)geo.tiles_per_b * a.B;
-    if (ntiles > 0) {
-        hipLaunchKernelGGL(msmv_bwd_owner_dfeat, dim3((unsigned)ntiles), dim3(OWN_THREADS), 0, s, a, ws, geo);
-        if ((e = hipGetLastError()) != hipSuccess)
-            return e;
+    const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
+    switch (a.P) {
+    case 1: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<1>, grid, block, 0, s, a, ws, geo); break;
+    case 2: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<2>, grid, block, 0, s, a, ws, geo); break;
+    case 4: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<4>, grid, block, 0, s, a, ws, geo); break;
+    default: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<0>, grid, block, 0, s, a, ws, geo); break;
     }
+    if ((e = hipGetLastError()) != hipSuccess)
+        return e;
     if (a.npts > 0)
         return a.L == 4 ? launch_gather<4>(a, s) : launch_gather<5>(a, s);
     return hipSuccess;
