@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Benchmark of the msmv_sampling hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
+
+One "step" is one pass of the op over one batch of synthetic input that is already
+resident in HBM: by default one decoder layer's forward + backward at the OPUS-L sampling
+shape (B' = 32*batch slabs, Q = 4800, P = 2, 4 levels of 256x704 features, C = 64).  For
+N > 1 the driver launches one rank per GPU (torch.distributed.run); every rank works on
+its own batch, nothing is exchanged on the data path (weak scaling), the timed region is
+bracketed by a barrier + synchronize and the slowest rank's time is the job's time.
+
+Prints ONE JSON line on rank 0: whole-job sampled points/s, the roofline record of the
+dominant kernel (HIP-event durations measured inside the timed region, algorithmic bytes
+from the closed forms below), and - at N = 1 - the CPU baseline (the grid_sample
+formulation of oracle/torch_ref.py on the host cores, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from opus_amd import _lib  # noqa: E402
+from opus_amd.csrc import wrapper  # noqa: E402
+
+LEVELS = [(64, 176), (32, 88), (16, 44), (8, 22)]     # 256x704 input, strides 4..32
+N_VIEWS, CHANNELS = 6, 64
+SLABS_PER_SAMPLE = 32                                  # T=8 frames x G=4 channel groups
+VARIANTS = {"T": (600, 4), "S": (1200, 2), "M": (2400, 2), "L": (4800, 2)}
+HBM_PEAK_GBPS = 8000.0                                 # MI355X HBM3E, spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="L-fwdbwd",
+                    help="{T,S,M,L}-fwd | {T,S,M,L}-fwdbwd | decoder-L (6 layers fwd+bwd) | "
+                         "train-M (6 x (2 fwd + 1 bwd) + RCCL all-reduce of a 0.3 GB gradient)")
+    ap.add_argument("--batch", type=int, default=1, help="samples per GPU (B' = 32 * batch)")
+    ap.add_argument("--bwd-algo", default="owner", choices=["owner", "atomic"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(Bp, Q, P, seed, device, n_sets=1):
+    """Synthetic op inputs: N(0,1) features, every point in range at every level (so the
+    byte count below is exact), uniform views, softmax weights, N(0,1) upstream gradient."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    feats = [torch.randn((Bp, N_VIEWS, h, w, CHANNELS), generator=gen, device=device) for h, w in LEVELS]
+    sets = []
+    for _ in range(n_sets):
+        xy = torch.rand((Bp, Q, P, 2), generator=gen, device=device)
+        view = torch.randint(0, N_VIEWS, (Bp, Q, P, 1), generator=gen, device=device).float() / (N_VIEWS - 1)
+        loc = torch.cat([xy, view], -1).contiguous()
+        w = torch.softmax(torch.randn((Bp, Q, P, len(LEVELS)), generator=gen, device=device), -1)
+        g = torch.randn((Bp, Q, CHANNELS, P), generator=gen, device=device)
+        sets.append((loc, w, g))
+    return feats, sets
+
+
+def alg_bytes(npts, feat_bytes):
+    """Algorithmic (no-reuse) bytes per launch of each kernel, L = 4 levels, C = 64 fp32:
+    a corner vector is 256 B, 16 corners per point."""
+    L, C = len(LEVELS), CHANNELS
+    corner = L * 4 * C * 4                    # 4096 B of feature reads or d-feat updates per point
+    vec = C * 4                               # one 256-B output / gradient vector per point
+    small = 12 + 4 * L                        # loc + weights (or their gradients)
+    return {
+        "msmv_fwd_c64": npts * (corner + vec + small),
+        "msmv_bwd_owner_dfeat": npts * (vec + small + corner) + feat_bytes,
+        "msmv_bwd_gather_c64": npts * (corner + vec + small + small),
+        "msmv_bin_sort": npts * (12 + 12 + 16),
+        # whole passes, the figures the metric is quoted on
+        "forward": npts * (corner + vec + small),
+        "backward": npts * (vec + small + corner + corner + small) + feat_bytes,
+    }
+
+
+class Step:
+    """One decoder layer's forward (+ backward) with an event pair around every launch."""
+
+    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1):
+        self.feats, self.sets, self.do_bwd, self.n_fwd = feats, sets, do_bwd, n_fwd
+        self.algo = algo
+        loc, w, _ = sets[0]
+        self.dfeats = [torch.empty_like(f) for f in feats]
+        self.dloc, self.dw = torch.empty_like(loc), torch.empty_like(w)
+        flags = _lib.BWD_OWNER if algo == "owner" else _lib.BWD_ATOMIC
+        need = wrapper.backward_workspace_bytes(feats, loc, w, flags)
+        self.ws = torch.empty(max(need, 16), dtype=torch.uint8, device=loc.device)
+        self.events = []          # (kernel name, start, end)
+
+    def _timed(self, name, fn, record):
+        if record:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            self.events.append((name, a, b))
+        else:
+            fn()
+
+    def run(self, record=True):
+        for loc, w, g in self.sets:
+            for _ in range(self.n_fwd):
+                self._timed("msmv_fwd_c64", lambda: wrapper.msmv_forward(self.feats, loc, w), record)
+            if not self.do_bwd:
+                continue
+            args = (g, self.feats, loc, w, self.dfeats, self.dloc, self.dw, self.ws)
+            if self.algo == "owner":
+                for name, bit in (("msmv_bin_sort", _lib.BWD_STAGE_BIN),
+                                  ("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT),
+                                  ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
+                    self._timed(name, lambda bit=bit: wrapper.msmv_backward_into(
+                        *args, flags=_lib.BWD_OWNER | bit), record)
+            else:
+                self._timed("msmv_bwd_atomic(+clear)", lambda: wrapper.msmv_backward_into(
+                    *args, flags=_lib.BWD_ATOMIC), record)
+
+    def kernel_ms(self):
+        per = {}
+        for name, a, b in self.events:
+            per.setdefault(name, []).append(a.elapsed_time(b))
+        return {k: (statistics.mean(v), len(v)) for k, v in per.items()}
+
+
+def cpu_baseline(variant, do_bwd, slabs=8, reps=5):
+    """The reference's grid_sample formulation (oracle/torch_ref.py) on the host cores, on
+    `slabs` of the workload's 32 batch slabs; median of `reps` after one warm-up."""
+    from oracle import torch_ref
+    Q, P = VARIANTS[variant]
+    gen = torch.Generator().manual_seed(1234)
+    feats = [torch.randn((slabs, CHANNELS, N_VIEWS, h, w), generator=gen).requires_grad_(do_bwd)
+             for h, w in LEVELS]
+    xy = torch.rand((slabs, Q, P, 2), generator=gen)
+    view = torch.randint(0, N_VIEWS, (slabs, Q, P, 1), generator=gen).float() / (N_VIEWS - 1)
+    loc = torch.cat([xy, view], -1).requires_grad_(do_bwd)
+    w = torch.softmax(torch.randn((slabs, Q, P, len(LEVELS)), generator=gen), -1).requires_grad_(do_bwd)
+    g = torch.randn((slabs, Q, CHANNELS, P), generator=gen)
+    times = []
+    for i in range(reps + 1):
+        for t in feats + [loc, w]:
+            t.grad = None
+        t0 = time.perf_counter()
+        out = torch_ref.grid_sample_ref(feats, loc, w)
+        if do_bwd:
+            out.backward(g)
+        dt = time.perf_counter() - t0
+        if i:
+            times.append(dt)
+    npts = slabs * Q * P
+    return {"value": npts / statistics.median(times), "unit": "sampled points/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{slabs} of the {SLABS_PER_SAMPLE} batch slabs of the OPUS-{variant} workload "
+                      f"({npts} points), {'forward + backward' if do_bwd else 'forward'}, PyTorch grid_sample "
+                      f"formulation (oracle/torch_ref.py), median of {reps} runs after 1 warm-up"}
+
+
+def load_traffic(workload, kernel):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get(workload, {}).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run "
+                     f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    assert wrapper.MSMV_CUDA, "libopus_msmv.so is not loaded"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    # ---- workload
+    wl = args.workload
+    n_layers, n_fwd, allreduce_bytes = 1, 1, 0
+    if wl == "decoder-L":
+        variant, do_bwd, n_layers = "L", True, 6
+    elif wl == "train-M":
+        variant, do_bwd, n_layers, n_fwd, allreduce_bytes = "M", True, 6, 2, 300 * 1000 * 1000
+    else:
+        variant, mode = wl.split("-")
+        do_bwd = mode == "fwdbwd"
+        assert variant in VARIANTS and mode in ("fwd", "fwdbwd"), wl
+    Q, P = VARIANTS[variant]
+    Bp = SLABS_PER_SAMPLE * args.batch
+    feats, sets = make_inputs(Bp, Q, P, 1234 + rank, device, n_sets=n_layers)
+    step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd)
+    npts_step = Bp * Q * P * n_layers                    # sampled points per step per rank
+    feat_bytes = sum(f.numel() * 4 for f in feats)
+
+    grad_buckets, comm_stream = [], None
+    if allreduce_bytes and dist is not None:
+        bucket = 25 * 1000 * 1000 // 4
+        grad_buckets = [torch.zeros(bucket, device=device) for _ in range(allreduce_bytes // (bucket * 4))]
+        comm_stream = torch.cuda.Stream()
+
+    def one_step(record):
+        step.run(record)
+        if grad_buckets:
+            # the DDP gradient all-reduce of the training config: 25 MB buckets over RCCL on a
+            # side stream (it overlaps the next step's kernels; the op itself needs no collective)
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                for b in grad_buckets:
+                    dist.all_reduce(b)
+            torch.cuda.current_stream().wait_stream(comm_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        kms = step.kernel_ms()
+        ab = alg_bytes(Bp * Q * P, feat_bytes)
+        kernels = {}
+        for name, (ms, n) in kms.items():
+            rec = {"avg_us": ms * 1e3, "launches": n}
+            if name in ab:
+                rec["alg_bytes"] = ab[name]
+                rec["achieved_GBps"] = ab[name] / (ms * 1e-3) / 1e9
+            kernels[name] = rec
+        dominant = max(kms, key=lambda k: kms[k][0] * kms[k][1])
+        dom = kernels[dominant]
+        roofline = {"bound": "hbm", "kernel": dominant,
+                    "achieved": dom.get("achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": (dom["achieved_GBps"] / HBM_PEAK_GBPS) if "achieved_GBps" in dom else None,
+                    "traffic": load_traffic(wl, dominant),
+                    "alg_bytes_per_launch": dom.get("alg_bytes"), "avg_launch_us": dom["avg_us"],
+                    "note": "achieved = algorithmic (no-reuse) bytes / HIP-event launch time; "
+                            "features re-touched by several points are served from L2 / Infinity Cache"}
+        pass_bytes = (ab["forward"] * n_fwd + (ab["backward"] if do_bwd else 0)) * n_layers
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": "sampled points/sec (fwd+bwd) + % HBM roofline, OPUS-T/L shape, 1/2/4/8 GPUs",
+            "value": world * npts_step * args.steps / elapsed,
+            "unit": "sampled points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"OPUS-{variant} sampling shape, "
+                                   f"{'forward + backward' if do_bwd else 'forward'}"
+                                   f"{', %d decoder layers' % n_layers if n_layers > 1 else ''}"
+                                   f"{', 2 forwards per backward + gradient all-reduce' if wl == 'train-M' else ''}",
+                       "name": wl, "Q": Q, "P": P, "slabs_per_gpu": Bp, "views": N_VIEWS,
+                       "levels": LEVELS, "channels": CHANNELS,
+                       "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
+                       "parallelism": f"dp{world} (batch-parallel, no data-path collective)"},
+            "roofline": roofline,
+            "step_alg_GBps": pass_bytes / (ms_per_step * 1e-3) / 1e9,
+            "step_alg_frac_of_peak": pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(variant, do_bwd)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,14 @@ enum {
 /* OR-ed into `flags`: do not clear d feats first, add onto their current contents
  * (atomic algorithm only).  The reference always clears (msmv_sampling.cpp:244-247). */
 #define OPUS_MSMV_BWD_ACCUMULATE 0x10
+/* OR-ed into `flags` (owner algorithm only): run just the named stage(s) of the backward,
+ * so that a profiler or benchmark can time each kernel with events of its own.  The stages
+ * must be issued in this order on one stream with the same arguments and workspace; no
+ * stage bit set means all three.  No counterpart in the reference. */
+#define OPUS_MSMV_BWD_STAGE_BIN 0x100      /* sort the points into (batch, view, band) bins */
+#define OPUS_MSMV_BWD_STAGE_DFEAT 0x200    /* d feats, one owner per run of pixels */
+#define OPUS_MSMV_BWD_STAGE_GATHER 0x400   /* d loc and d weights */
+#define OPUS_MSMV_BWD_STAGE_MASK 0x700
 
 /* Library version (OPUS_MSMV_VERSION it was built with). */
 int opus_msmv_version(void);

@@ -14,6 +14,7 @@ OK = 0
 BWD_AUTO, BWD_ATOMIC, BWD_OWNER = 0, 1, 2
 BWD_ACCUMULATE = 0x10
 FWD_GENERIC = 0x1
+BWD_STAGE_BIN, BWD_STAGE_DFEAT, BWD_STAGE_GATHER = 0x100, 0x200, 0x400
 MAX_LEVELS = 8
 MAX_POINTS = 32
 

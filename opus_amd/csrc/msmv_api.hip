@@ -146,7 +146,10 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
         return rc;
     const int algo = flags & 0xF;
     const bool accumulate = (flags & OPUS_MSMV_BWD_ACCUMULATE) != 0;
-    if ((flags & ~(0xF | OPUS_MSMV_BWD_ACCUMULATE)) || algo > OPUS_MSMV_BWD_OWNER)
+    const int stage_bits = flags & OPUS_MSMV_BWD_STAGE_MASK;
+    if ((flags & ~(0xF | OPUS_MSMV_BWD_ACCUMULATE | OPUS_MSMV_BWD_STAGE_MASK)) || algo > OPUS_MSMV_BWD_OWNER)
+        return OPUS_MSMV_EINVAL_FLAGS;
+    if (stage_bits && algo != OPUS_MSMV_BWD_OWNER)
         return OPUS_MSMV_EINVAL_FLAGS;
     if (accumulate && algo == OPUS_MSMV_BWD_OWNER)
         return OPUS_MSMV_EINVAL_FLAGS;
@@ -184,7 +187,7 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
         const size_t need = msmv_backward_owner_workspace(B, N, Q, P);
         if (!workspace || workspace_bytes < need || !aligned16(workspace))
             return OPUS_MSMV_EWORKSPACE;
-        e = msmv_launch_backward_owner(a, workspace, (hipStream_t)stream);
+        e = msmv_launch_backward_owner(a, workspace, (hipStream_t)stream, stage_bits ? stage_bits >> 8 : 7);
     } else {
         e = msmv_launch_backward_atomic(a, (hipStream_t)stream, accumulate);
     }

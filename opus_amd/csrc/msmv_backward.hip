@@ -574,7 +574,7 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
     return owner_ws_header_bytes(B, N) + (size_t)B * Q * P * sizeof(BinEntry);
 }
 
-hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s)
+hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages)
 {
     OwnerWs ws;
     ws.offsets = reinterpret_cast<int *>(workspace);
@@ -582,9 +582,11 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     ws.keys = a.N * BIN_PER_VIEW;
 
     hipError_t e;
-    hipLaunchKernelGGL(msmv_bin_sort, dim3(a.B), dim3(BIN_THREADS), 0, s, a, ws);
-    if ((e = hipGetLastError()) != hipSuccess)
-        return e;
+    if (stages & 1) {
+        hipLaunchKernelGGL(msmv_bin_sort, dim3(a.B), dim3(BIN_THREADS), 0, s, a, ws);
+        if ((e = hipGetLastError()) != hipSuccess)
+            return e;
+    }
 
     OwnerGeom geo = {};
     int per_view = 0;
@@ -595,7 +597,8 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     geo.tiles_per_b = per_view * a.N;
     const long long ntiles = (long long)geo.tiles_per_b * a.B;
     const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
-    switch (a.P) {
+    switch ((stages & 2) ? a.P : -1) {
+    case -1: break;
     case 1: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<1>, grid, block, 0, s, a, ws, geo); break;
     case 2: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<2>, grid, block, 0, s, a, ws, geo); break;
     case 4: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<4>, grid, block, 0, s, a, ws, geo); break;
@@ -603,7 +606,7 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     }
     if ((e = hipGetLastError()) != hipSuccess)
         return e;
-    if (a.npts > 0)
+    if (a.npts > 0 && (stages & 4))
         return a.L == 4 ? launch_gather<4>(a, s) : launch_gather<5>(a, s);
     return hipSuccess;
 }

@@ -12,4 +12,5 @@ hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool ac
 // Owner-computes backward (C == 64 only).
 bool msmv_backward_owner_supported(const MsmvArgs &a);
 size_t msmv_backward_owner_workspace(int B, int N, int Q, int P);
-hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s);
+// stages: bit 0 = bin, bit 1 = d feat tiles, bit 2 = d loc / d w gather
+hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages);

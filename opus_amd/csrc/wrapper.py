@@ -133,12 +133,40 @@ def msmv_forward(feats, loc, w, flags=0):
     return out
 
 
-def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None):
-    """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them."""
+def backward_workspace_bytes(feats, loc, w, flags=0):
+    """Device scratch the backward needs for these tensors (0 for the atomic algorithm)."""
+    L, B, C, N, Q, P, _ = _check_inputs(feats, loc, w)
+    return _lib.load().opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags)
+
+
+def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None, flags=0):
+    """Raw backward into caller-owned buffers (no allocation here when ``workspace`` is
+    given).  ``flags``: algorithm | ACCUMULATE | STAGE_* bits of include/opus_msmv.h."""
     L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
     if not grad_out.is_contiguous() or tuple(grad_out.shape) != (B, Q, C, P) \
             or grad_out.dtype != torch.float32 or grad_out.device != loc.device:
         raise RuntimeError("grad_output must be a contiguous float32 [B,Q,C,P] tensor on the inputs' device")
+    for d, f in zip(dfeats, feats):
+        if d.shape != f.shape or not d.is_contiguous() or d.dtype != torch.float32 or d.device != f.device:
+            raise RuntimeError("d feats must match feats in shape, dtype and device and be contiguous")
+    if dloc.shape != loc.shape or dw.shape != w.shape or not dloc.is_contiguous() or not dw.is_contiguous():
+        raise RuntimeError("dloc / dweights must match sampling_loc / attn_weight and be contiguous")
+    lib = _lib.load()
+    with torch.cuda.device(loc.device):
+        need = lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags)
+        if workspace is None:
+            workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=loc.device)
+        rc = lib.opus_msmv_backward(
+            L, grad_out.data_ptr(), _lib.ptr_array([f.data_ptr() for f in feats]),
+            _lib.int_array(hw), loc.data_ptr(), w.data_ptr(), B, C, N, Q, P,
+            _lib.ptr_array([d.data_ptr() for d in dfeats]), dloc.data_ptr(), dw.data_ptr(),
+            workspace.data_ptr(), workspace.numel() * workspace.element_size(), flags,
+            _stream_ptr(loc.device))
+    _lib.check(rc, "opus_msmv_backward")
+
+
+def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None):
+    """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them."""
     flags = _BWD_ALGOS[_bwd_algo if algo is None else algo]
     if dfeats is None:
         dfeats = [torch.empty_like(f) for f in feats]
@@ -146,16 +174,7 @@ def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None):
         flags = _lib.BWD_ATOMIC | _lib.BWD_ACCUMULATE
     dloc = torch.empty_like(loc)
     dw = torch.empty_like(w)
-    lib = _lib.load()
-    with torch.cuda.device(loc.device):
-        need = lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags)
-        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=loc.device)
-        rc = lib.opus_msmv_backward(
-            L, grad_out.data_ptr(), _lib.ptr_array([f.data_ptr() for f in feats]),
-            _lib.int_array(hw), loc.data_ptr(), w.data_ptr(), B, C, N, Q, P,
-            _lib.ptr_array([d.data_ptr() for d in dfeats]), dloc.data_ptr(), dw.data_ptr(),
-            ws.data_ptr(), need, flags, _stream_ptr(loc.device))
-    _lib.check(rc, "opus_msmv_backward")
+    msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, flags=flags)
     return dfeats, dloc, dw
 
 
