@@ -93,10 +93,10 @@ msmv_bwd_atomic(const MsmvArgs a)
 // ======================================================================================
 // owner algorithm: binning
 // ======================================================================================
-struct BinEntry {       // 16 bytes, one aligned load
+struct BinEntry {       // 32 bytes: everything the d-feat pass needs about a point
     int pt;
     float x, y;
-    int pad;
+    float w[5];         // the point's scale weights (L <= 5; unused slots are 0)
 };
 
 constexpr int BIN_YB = 16;               // y-bands per (batch, view)
@@ -105,7 +105,7 @@ constexpr int BIN_PER_VIEW = BIN_YB * BIN_XB;
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_KEYS = 2048;       // N * BIN_PER_VIEW must not exceed this
 
-// workspace layout: [ offsets: B * (keys+1) ints, padded to 256 B ][ entries: npts * 16 B ]
+// workspace layout: [ offsets: B * (keys+1) ints, padded to 256 B ][ entries: npts * 32 B ]
 // entries of batch b occupy [b*QP, b*QP + offsets[b][keys]), sorted by
 // key = (view*BIN_YB + yband)*BIN_XB + xband; offsets[b][k] is the exclusive prefix of the
 // key counts of batch b.
@@ -196,9 +196,14 @@ msmv_bin_sort(const MsmvArgs a, OwnerWs ws)
         const int view = msmv_view_of(lp[2], a.N);
         if (view >= 0) {
             const int slot = atomicAdd(&hist[(view * BIN_YB + msmv_band_of<BIN_YB>(y)) * BIN_XB + msmv_band_of<BIN_XB>(x)], 1);
-            int4 e;
-            e.x = (int)(pt0 + i); e.y = __float_as_int(x); e.z = __float_as_int(y); e.w = 0;
-            *reinterpret_cast<int4 *>(dst + slot) = e;
+            const float *wp = a.w + (pt0 + i) * a.L;
+            float wv[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                wv[k] = k < a.L ? wp[k] : 0.f;
+            float4 *e = reinterpret_cast<float4 *>(dst + slot);
+            e[0] = make_float4(__int_as_float((int)(pt0 + i)), x, y, wv[0]);
+            e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
         }
     }
 }
@@ -209,78 +214,82 @@ msmv_bin_sort(const MsmvArgs a, OwnerWs ws)
 // LDS float atomics (ds_add_f32) cost ~190 LDS cycles per wave instruction on gfx950, so
 // no two waves ever share a pixel: each WAVE owns a run of SUB_PIX consecutive pixels of one
 // (batch, view, level) slab, keeps it in its private slice of LDS and updates it with plain
-// ds_read_b128 / ds_write_b128.  A hit (a point with at least one corner in the run) is
-// handled by the whole wave at once: row r of 16 lanes takes corner r, each lane 4 channels.
-constexpr int SUB_PIX = 22;              // pixels per wave: 22 * 256 B = 5.5 KiB of LDS
+// ds_read_b32 / ds_write_b32.  A hit (a point with at least one corner in the run) is
+// handled by the whole wave, lane = channel: one coalesced load of the point's gradient
+// vector, then four read-modify-writes issued together (the corners of a point are distinct
+// pixels).  A corner outside the run is redirected, with weight 0, to a spare pixel slot
+// behind the run, which keeps the hit loop free of branches and of per-corner LDS waits.
+constexpr int SUB_PIX = 22;              // pixels per wave: (22 + 1 spare) * 256 B = 5.75 KiB of LDS
 constexpr int OWN_WAVES = 8;
 constexpr int OWN_THREADS = OWN_WAVES * 64;
-constexpr int TILE_PIX = SUB_PIX * OWN_WAVES;   // 176 pixels = 44 KiB per workgroup, 3 workgroups per CU
-constexpr int OWN_BATCH = 4;             // hits whose gradient vectors are in flight together
+constexpr int TILE_PIX = SUB_PIX * OWN_WAVES;   // 176 pixels, 46 KiB of LDS per workgroup, 3 workgroups per CU
+constexpr int OWN_BATCH = 8;             // hits whose gradient vectors are in flight together
 
 struct OwnerGeom {
     int tiles_per_level[MSMV_MAX_LEVELS];   // workgroups per (batch, view) slab of the level
     int tiles_per_b;                         // N * sum over levels
 };
 
-// Gradient vector of one point for this lane's 4 channels (4*l16 .. 4*l16+3).  grad_out is
-// [B,Q,C,P]: for P in {1,2,4} the lane's 4*P floats are contiguous and fetched with 16-byte
-// loads (the P-strided dword form runs at about one lane per cycle).
+// grad_out[b,q,lane,p] of point pt for channel = lane.  grad_out is [B,Q,C,P]: for P in
+// {1,2,4} the P floats of a channel are fetched with one 4/8/16-byte load (a wave reads
+// 256*P contiguous bytes) and the point's p is picked afterwards; the generic form is a
+// P-strided dword load.
 template <int PT>
-__device__ __forceinline__ void msmv_load_grad(const MsmvArgs &a, int pt, int l16, float4 (&v)[PT == 0 ? 1 : PT])
+struct GradRaw { float v[PT == 0 ? 1 : PT]; };
+
+template <int PT>
+__device__ __forceinline__ GradRaw<PT> msmv_load_grad(const MsmvArgs &a, int pt, int lane)
 {
+    GradRaw<PT> r;
     if constexpr (PT == 0) {
         const int bq = pt / a.P, p = pt - bq * a.P;
-        const float *gp = a.gout + ((size_t)bq * 64 + l16 * 4) * a.P + p;
-        v[0] = make_float4(gp[0], gp[(size_t)a.P], gp[(size_t)a.P * 2], gp[(size_t)a.P * 3]);
+        r.v[0] = a.gout[((size_t)bq * 64 + lane) * a.P + p];
+    } else if constexpr (PT == 1) {
+        r.v[0] = a.gout[(size_t)pt * 64 + lane];
+    } else if constexpr (PT == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(a.gout + ((size_t)(pt >> 1) * 64 + lane) * 2);
+        r.v[0] = t.x; r.v[1] = t.y;
     } else {
-        const float4 *gp = reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt / PT) * 64 + l16 * 4) * PT);
-#pragma unroll
-        for (int k = 0; k < PT; ++k)
-            v[k] = gp[k];
+        const float4 t = *reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 2) * 64 + lane) * 4);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
     }
+    return r;
 }
 
 template <int PT>
-__device__ __forceinline__ float4 msmv_select_grad(const float4 (&v)[PT == 0 ? 1 : PT], int pt)
+__device__ __forceinline__ float msmv_select_grad(const GradRaw<PT> &r, int pt)
 {
-    // component-wise selects on named values: selecting between whole vectors by a scalar
-    // makes hipcc spill the array to scratch and index it
     if constexpr (PT == 0 || PT == 1) {
-        return v[0];
+        return r.v[0];
     } else if constexpr (PT == 2) {
-        const bool odd = pt & 1;
-        const float4 A = v[0], B = v[1];
-        float4 r;
-        r.x = odd ? A.y : A.x;
-        r.y = odd ? A.w : A.z;
-        r.z = odd ? B.y : B.x;
-        r.w = odd ? B.w : B.z;
-        return r;
+        const float x = r.v[0], y = r.v[1];
+        return (pt & 1) ? y : x;
     } else {
-        const bool p1 = pt & 1, p2 = pt & 2;
-        float4 r;
-#define MSMV_PICK(V) (p2 ? (p1 ? (V).w : (V).z) : (p1 ? (V).y : (V).x))
-        const float4 A = v[0], B = v[1], C = v[2], D = v[3];
-        r.x = MSMV_PICK(A);
-        r.y = MSMV_PICK(B);
-        r.z = MSMV_PICK(C);
-        r.w = MSMV_PICK(D);
-#undef MSMV_PICK
-        return r;
+        const float x = r.v[0], y = r.v[1], z = r.v[2], w = r.v[3];
+        return (pt & 2) ? ((pt & 1) ? w : z) : ((pt & 1) ? y : x);
     }
 }
+
+// What one lane knows about the bin entry it scanned (one point against this wave's run).
+struct OwnHit {
+    int pt;
+    bool hit;                        // at least one corner lies in the run
+    unsigned co12, co34;             // LDS byte offsets of the corners' pixels, two 16-bit fields each
+    float cw1, cw2, cw3, cw4;        // corner weight * scale weight (0 for a corner outside the run)
+};
 
 template <int PT>
 __global__ void __launch_bounds__(OWN_THREADS)
 msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 {
-    constexpr int BATCH = PT == 4 ? 2 : OWN_BATCH;
-    __shared__ float4 tile_all[OWN_WAVES][SUB_PIX * 16];
+    constexpr int BATCH = OWN_BATCH;
+    __shared__ float4 tile_all[OWN_WAVES][(SUB_PIX + 1) * 16];
 
     const int lane = threadIdx.x & 63;
-    const int row = lane >> 4, l16 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *tile = tile_all[wave];
+    char *tileb = reinterpret_cast<char *>(tile) + lane * 4;    // this lane's channel column
+    constexpr unsigned SPARE = SUB_PIX * 256;                   // byte offset of the spare pixel
 
     // ---- which run of pixels: logical order [b][level, coarse first][view][tile][wave]
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
@@ -305,49 +314,92 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     for (int i = lane; i < npix * 16; i += 64)
         tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- the bins that can reach this run
+    // ---- the bins that can reach this run: one segment of the sorted entries per y-band
+    // (all of them adjacent, i.e. one segment, when every x-band is wanted)
     const int r0 = s0 / W, r1 = (s0 + npix - 1) / W;
     int yb_lo, yb_hi, xb_lo = 0, xb_hi = BIN_XB - 1;
     msmv_band_range<BIN_YB>(r0, r1, H, yb_lo, yb_hi);
     if (r0 == r1)
         msmv_band_range<BIN_XB>(s0 - r0 * W, s0 + npix - 1 - r0 * W, W, xb_lo, xb_hi);
     const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
+    const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB = 16
     const int *off = ws.offsets + (size_t)b * (ws.keys + 1) + view * BIN_PER_VIEW;
-    const int4 *list = reinterpret_cast<const int4 *>(ws.entries + (size_t)b * a.qp);
-    // with every x-band wanted the y-bands' segments are adjacent: one segment in all
-    const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;
+    const float4 *list = reinterpret_cast<const float4 *>(ws.entries + (size_t)b * a.qp);
+
+    // Lane s holds segment s: its length, the count of entries before it (excl) and
+    // delta = begin - excl, so that virtual entry v of the concatenation is list[v + delta].
+    int seg_len = 0, seg_begin = 0;
+    if (lane < nseg) {
+        const int k_lo = all_x ? yb_lo * BIN_XB : (yb_lo + lane) * BIN_XB + xb_lo;
+        const int k_hi = all_x ? (yb_hi + 1) * BIN_XB : (yb_lo + lane) * BIN_XB + xb_hi + 1;
+        seg_begin = off[k_lo];
+        seg_len = off[k_hi] - seg_begin;
+    }
+    int incl = seg_len;
+#pragma unroll
+    for (int d = 1; d < BIN_YB; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d)
+            incl += up;
+    }
+    const int seg_excl = incl - seg_len;
+    const int seg_delta = seg_begin - seg_excl;
+    const int total = __builtin_amdgcn_readlane(incl, nseg - 1);
+
+    // entry index of virtual entry v (clamped into range so that every lane loads something)
+    auto entry_index = [&](int v0) {
+        const int v = min(v0 + lane, total - 1);
+        int idx = v + __builtin_amdgcn_readlane(seg_delta, 0);
+        for (int sgm = 1; sgm < nseg; ++sgm) {
+            const int cs = __builtin_amdgcn_readlane(seg_excl, sgm);
+            const int ds = __builtin_amdgcn_readlane(seg_delta, sgm);
+            idx = v >= cs ? v + ds : idx;
+        }
+        return idx;
+    };
+    // weight l of an entry sits in dword 3 + l
+    auto load_entry = [&](int idx, float4 &e0, float &wl) {
+        e0 = list[(size_t)idx * 2];
+        wl = reinterpret_cast<const float *>(list + (size_t)idx * 2)[3 + l];
+    };
+    auto scan = [&](int v0, const float4 &e0, float wl) {
+        OwnHit h;
+        const bool valid = v0 + lane < total;
+        h.pt = __float_as_int(e0.x);
+        const MsmvTap t = msmv_make_tap(e0.y, e0.z, H, W, valid);
+        const bool in1 = t.c1 && (unsigned)(t.o1 - s0) < (unsigned)npix;
+        const bool in2 = t.c2 && (unsigned)(t.o2 - s0) < (unsigned)npix;
+        const bool in3 = t.c3 && (unsigned)(t.o3 - s0) < (unsigned)npix;
+        const bool in4 = t.c4 && (unsigned)(t.o4 - s0) < (unsigned)npix;
+        h.hit = in1 || in2 || in3 || in4;
+        const unsigned b1 = in1 ? (unsigned)(t.o1 - s0) * 256u : SPARE;
+        const unsigned b2 = in2 ? (unsigned)(t.o2 - s0) * 256u : SPARE;
+        const unsigned b3 = in3 ? (unsigned)(t.o3 - s0) * 256u : SPARE;
+        const unsigned b4 = in4 ? (unsigned)(t.o4 - s0) * 256u : SPARE;
+        h.co12 = b1 | (b2 << 16);
+        h.co34 = b3 | (b4 << 16);
+        h.cw1 = in1 ? t.w1 * wl : 0.f;
+        h.cw2 = in2 ? t.w2 * wl : 0.f;
+        h.cw3 = in3 ? t.w3 * wl : 0.f;
+        h.cw4 = in4 ? t.w4 * wl : 0.f;
+        return h;
+    };
 
 #ifdef MSMV_ABL_NOSCAN
     if (false)
 #endif
-    for (int sg = 0; sg < nseg; ++sg) {
-        const int k_lo = all_x ? yb_lo * BIN_XB : (yb_lo + sg) * BIN_XB + xb_lo;
-        const int k_hi = all_x ? (yb_hi + 1) * BIN_XB : (yb_lo + sg) * BIN_XB + xb_hi + 1;
-        const int seg_begin = off[k_lo], seg_end = off[k_hi];
+    if (total > 0) {
+        float4 e0;
+        float wl;
+        load_entry(entry_index(0), e0, wl);
+        for (int v0 = 0; v0 < total; v0 += 64) {
+            const OwnHit h = scan(v0, e0, wl);
+            if (v0 + 64 < total)                               // next chunk's entries, in flight
+                load_entry(entry_index(v0 + 64), e0, wl);      // while this chunk's hits are applied
 
-        for (int i0 = seg_begin; i0 < seg_end; i0 += 64) {
-            const int i = i0 + lane;
-            const bool valid = i < seg_end;
-            const int4 cur = list[valid ? i : seg_end - 1];
-            const int pt = cur.x;
-            const MsmvTap t = msmv_make_tap(__int_as_float(cur.y), __int_as_float(cur.z), H, W, valid);
-            // corners that fall into this wave's run of pixels
-            const bool in1 = t.c1 && (unsigned)(t.o1 - s0) < (unsigned)npix;
-            const bool in2 = t.c2 && (unsigned)(t.o2 - s0) < (unsigned)npix;
-            const bool in3 = t.c3 && (unsigned)(t.o3 - s0) < (unsigned)npix;
-            const bool in4 = t.c4 && (unsigned)(t.o4 - s0) < (unsigned)npix;
-            const bool hit = in1 || in2 || in3 || in4;
-            float wl = 0.f;
-            if (hit)
-                wl = a.w[(size_t)pt * a.L + l];
-            // float4 index of the corner's pixel inside the run, or -1
-            const int co1 = in1 ? (t.o1 - s0) * 16 : -1, co2 = in2 ? (t.o2 - s0) * 16 : -1;
-            const int co3 = in3 ? (t.o3 - s0) * 16 : -1, co4 = in4 ? (t.o4 - s0) * 16 : -1;
-            const float cw1 = t.w1 * wl, cw2 = t.w2 * wl, cw3 = t.w3 * wl, cw4 = t.w4 * wl;
-
-            unsigned long long hits = __ballot(hit);
+            unsigned long long hits = __ballot(h.hit);
 #ifdef MSMV_ABL_NOHITS
-            asm volatile("" ::"v"(co1), "v"(co2), "v"(co3), "v"(co4), "v"(cw1), "v"(cw2), "v"(cw3), "v"(cw4));
+            asm volatile("" ::"v"(h.co12), "v"(h.co34), "v"(h.cw1), "v"(h.cw2), "v"(h.cw3), "v"(h.cw4));
             hits = 0;
 #endif
             while (hits) {
@@ -357,40 +409,37 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                     j[u] = hits ? __ffsll((long long)hits) - 1 : -1;
                     hits &= hits - 1;                      // 0 stays 0
                 }
-                float4 gv[BATCH][PT == 0 ? 1 : PT];
+                GradRaw<PT> gv[BATCH];
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
                     // an empty slot re-reads the first hit's vector: no branch around the loads
-                    hpt[u] = __builtin_amdgcn_readlane(pt, j[u] >= 0 ? j[u] : j[0]);
-                    msmv_load_grad<PT>(a, hpt[u], l16, gv[u]);
+                    hpt[u] = __builtin_amdgcn_readlane(h.pt, j[u] >= 0 ? j[u] : j[0]);
+                    gv[u] = msmv_load_grad<PT>(a, hpt[u], lane);
                 }
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) {
                     if (j[u] >= 0) {
                         const int J = j[u];
-                        const float4 gu = msmv_select_grad<PT>(gv[u], hpt[u]);
-                        const int o1 = __builtin_amdgcn_readlane(co1, J), o2 = __builtin_amdgcn_readlane(co2, J);
-                        const int o3 = __builtin_amdgcn_readlane(co3, J), o4 = __builtin_amdgcn_readlane(co4, J);
-                        const float k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw1), J));
-                        const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw2), J));
-                        const float k3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw3), J));
-                        const float k4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cw4), J));
-                        // row r of the wave takes corner r; the four corners are distinct pixels
-                        const int o = row == 0 ? o1 : row == 1 ? o2 : row == 2 ? o3 : o4;
-                        const float k = row == 0 ? k1 : row == 1 ? k2 : row == 2 ? k3 : k4;
+                        const float gu = msmv_select_grad<PT>(gv[u], hpt[u]);
+                        const unsigned o12 = __builtin_amdgcn_readlane(h.co12, J), o34 = __builtin_amdgcn_readlane(h.co34, J);
+                        const float k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw1), J));
+                        const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw2), J));
+                        const float k3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw3), J));
+                        const float k4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw4), J));
 #ifdef MSMV_ABL_NORMW
-                        asm volatile("" ::"v"(k), "v"(o), "v"(gu.x), "v"(gu.y), "v"(gu.z), "v"(gu.w));
-                        if (false) {
+                        asm volatile("" ::"s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(o12), "s"(o34), "v"(gu));
 #else
-                        if (o >= 0) {
+                        float *p1 = reinterpret_cast<float *>(tileb + (o12 & 0xFFFFu));
+                        float *p2 = reinterpret_cast<float *>(tileb + (o12 >> 16));
+                        float *p3 = reinterpret_cast<float *>(tileb + (o34 & 0xFFFFu));
+                        float *p4 = reinterpret_cast<float *>(tileb + (o34 >> 16));
+                        // read all four, then write all four: in-run corners are distinct pixels
+                        const float v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;
+                        *p1 = v1 + k1 * gu;
+                        *p2 = v2 + k2 * gu;
+                        *p3 = v3 + k3 * gu;
+                        *p4 = v4 + k4 * gu;
 #endif
-                            float4 acc = tile[o + l16];
-                            acc.x += k * gu.x;
-                            acc.y += k * gu.y;
-                            acc.z += k * gu.z;
-                            acc.w += k * gu.w;
-                            tile[o + l16] = acc;
-                        }
                     }
                 }
             }
