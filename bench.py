@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from opus_amd import _lib  # noqa: E402
+from opus_amd import dist as odist  # noqa: E402
 from opus_amd.csrc import wrapper  # noqa: E402
 
 LEVELS = [(64, 176), (32, 88), (16, 44), (8, 22)]     # 256x704 input, strides 4..32
@@ -179,9 +180,7 @@ def load_traffic(workload, kernel):
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = odist.env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run "
@@ -191,11 +190,7 @@ def main():
     assert wrapper.MSMV_CUDA, "libopus_msmv.so is not loaded"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    dist = odist.init("nccl", device)       # "nccl" is RCCL on ROCm; None when single-process
 
     # ---- workload
     wl = args.workload
@@ -232,24 +227,14 @@ def main():
                     dist.all_reduce(b)
             torch.cuda.current_stream().wait_stream(comm_stream)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         one_step(False)
-    fence()
+    odist.fence(dist, device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    odist.fence(dist, device)
+    elapsed = odist.max_over_ranks(time.perf_counter() - t0, dist, device)
 
     if rank == 0:
         kms = step.kernel_ms()

@@ -1,0 +1,70 @@
+"""One-process-per-GPU helpers for the sampling op.
+
+The op is embarrassingly parallel over its batch dimension B' = B*T*G: every slab reads only
+its own feature maps, locations and weights and writes only its own outputs / gradients
+(reference kernels: msmv_sampling_forward.cu:96-101,127; msmv_sampling_backward.cu:135-142).
+Multi-GPU execution therefore shards slabs (or whole samples, as the reference's DDP does,
+train.py:93) across ranks with NO collective on the data path; torch.distributed (RCCL on
+ROCm) is used only for rendezvous, barriers, timing reductions and - in a training
+configuration - the parameter-gradient all-reduce that lives outside the op.
+"""
+import os
+
+import torch
+
+
+def env_rank():
+    """(rank, world_size, local_rank) from the launcher's environment (1 process if unset)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend, device=None):
+    """Initialise the default process group if WORLD_SIZE > 1; returns torch.distributed or None."""
+    _, world, _ = env_rank()
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        kwargs = {}
+        if device is not None and backend == "nccl":
+            kwargs["device_id"] = device
+        dist.init_process_group(backend, **kwargs)
+    return dist
+
+
+def shard_range(n_items, world, rank):
+    """Contiguous, balanced [start, stop) of `n_items` for `rank`: the first n_items % world
+    ranks get one extra item; ranks beyond n_items get an empty range."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_slabs(tensors, world, rank):
+    """Slice every tensor's leading (slab) dimension to this rank's range."""
+    n = tensors[0].shape[0]
+    lo, hi = shard_range(n, world, rank)
+    return [t[lo:hi].contiguous() for t in tensors]
+
+
+def max_over_ranks(value, dist, device):
+    """The slowest rank's value (e.g. elapsed seconds)."""
+    if dist is None:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def fence(dist, device=None):
+    """synchronize + barrier + synchronize: both sides of a timed region."""
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)

@@ -1,0 +1,92 @@
+"""Caller of the sampling op: mirror of the reference's ``models/opus_sampling.py``.
+
+``sampling_4d`` keeps the reference's signature and semantics (models/opus_sampling.py:19-124):
+project every 3-D sampling point into the T*N camera views, keep the first view in which
+it is visible, pack points and scale weights with (frame, group) folded into the batch
+dimension, run ``msmv_sampling`` and unpack to [B, Q, G, T*P, C].
+
+Two inherited behaviours are reproduced on purpose, because trained weights depend on them:
+  * points are packed in (B, T, G) order but scale weights in (B, G, T) order
+    (opus_sampling.py:104-106 vs :110-112), so row i of the weights is not the (t, g) of
+    row i of the points whenever T != G;
+  * the visibility mask only selects the view; a point visible in no camera is still
+    sampled in camera 0 at wherever it projects (opus_sampling.py:94-98) and relies on the
+    op's zero padding.
+
+Feature maps are expected in the layout the HIP op takes, [B*T*G, N, H, W, C] (channel-last),
+i.e. what the reference's decoder prepares when MSMV_CUDA is true
+(models/opus_transformer.py:119-121); ``relayout_features`` restates that step.
+"""
+import torch
+
+from .csrc.wrapper import msmv_sampling
+
+
+def relayout_features(mlvl_feats, num_frames, num_views, num_groups):
+    """[B, T*N, G*C, H, W] per level -> [B*T*G, N, H, W, C] contiguous (channel-last).
+
+    Restates models/opus_transformer.py:113-121: channel index = g*C + c, image index = t*N + n.
+    """
+    out = []
+    for feat in mlvl_feats:
+        B, TN, GC, H, W = feat.shape
+        T, N, G = num_frames, num_views, num_groups
+        assert TN == T * N and GC % G == 0
+        C = GC // G
+        feat = feat.reshape(B, T, N, G, C, H, W).permute(0, 1, 3, 2, 5, 6, 4)
+        out.append(feat.reshape(B * T * G, N, H, W, C).contiguous())
+    return out
+
+
+def project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
+    """Everything ``sampling_4d`` does before the op (opus_sampling.py:36-113).
+
+    sample_points [B, Q, T, G, P, 3] (metres), scale_weights [B, Q, G, T, P, L],
+    occ2img [B, T*N, 4, 4].  Returns (loc [B*T*G, Q, P, 3], weights [B*G*T, Q, P, L]).
+    """
+    B, Q, T, G, P, _ = sample_points.shape
+    N = num_views
+    GP = G * P
+    pts = sample_points.reshape(B, Q, T, GP, 3)
+    pts = torch.cat([pts, torch.ones_like(pts[..., :1])], dim=-1)            # homogeneous
+    pts = pts.permute(0, 2, 1, 3, 4)                                           # [B, T, Q, GP, 4]
+    mats = occ2img.reshape(B, T, N, 4, 4)
+    # cam[b,t,n,q,k,i] = sum_j mats[b,t,n,i,j] * pts[b,t,q,k,j]   (opus_sampling.py:54)
+    cam = torch.matmul(mats[:, :, :, None, None], pts[:, :, None, ..., None]).squeeze(-1)
+
+    homo = cam[..., 2:3]
+    homo_nonzero = torch.maximum(homo, torch.zeros_like(homo) + eps)           # :58
+    uv = cam[..., 0:2] / homo_nonzero                                          # :59
+    uv = torch.stack([uv[..., 0] / image_w, uv[..., 1] / image_h], dim=-1)     # :62-63
+
+    valid = ((homo > eps) & (uv[..., 1:2] > 0.0) & (uv[..., 1:2] < 1.0)
+             & (uv[..., 0:1] > 0.0) & (uv[..., 0:1] < 1.0)).squeeze(-1).float()   # [B, T, N, Q, GP]
+    valid = valid.permute(0, 1, 3, 4, 2)                                       # [B, T, Q, GP, N]
+    uv = uv.permute(0, 1, 3, 4, 2, 5)                                          # [B, T, Q, GP, N, 2]
+
+    # first valid camera, camera 0 if none (argmax of a 0/1 mask, opus_sampling.py:94)
+    i_view = torch.argmax(valid, dim=-1, keepdim=True)                         # [B, T, Q, GP, 1]
+    uv = torch.gather(uv, 4, i_view[..., None].expand(B, T, Q, GP, 1, 2)).squeeze(4)
+    loc = torch.cat([uv, i_view.float() / (N - 1)], dim=-1)                    # [B, T, Q, GP, 3]
+
+    loc = loc.reshape(B, T, Q, G, P, 3).permute(0, 1, 3, 2, 4, 5)              # (B, T, G) order
+    loc = loc.reshape(B * T * G, Q, P, 3).contiguous()
+    w = scale_weights.reshape(B, Q, G, T, P, -1).permute(0, 2, 3, 1, 4, 5)     # (B, G, T) order
+    w = w.reshape(B * G * T, Q, P, -1).contiguous()
+    return loc, w
+
+
+def unpack(final, B, T, G):
+    """[B*T*G, Q, C, P] -> [B, Q, G, T*P, C] (opus_sampling.py:119-122)."""
+    _, Q, C, P = final.shape
+    final = final.reshape(B, T, G, Q, C, P).permute(0, 3, 2, 1, 5, 4)
+    return final.flatten(3, 4)
+
+
+def sampling_4d(sample_points, mlvl_feats, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
+    """Same contract as the reference's sampling_4d with channel-last features
+    [B*T*G, N, H, W, C]; returns [B, Q, G, T*P, C]."""
+    B, Q, T, G, P, _ = sample_points.shape
+    loc, w = project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
+    final = msmv_sampling(mlvl_feats, loc, w)
+    return unpack(final, B, T, G)

@@ -205,6 +205,17 @@ def test_non_default_stream_and_accumulate(wr, oracle):
         assert_close(d.cpu().numpy(), 2 * ref_df[i], GRAD_RTOL, f"accumulated dfeat{i}")
 
 
+def test_sampling_4d_matches_golden(wr):
+    """The caller restatement + HIP op against the reference's sampling_4d output."""
+    from opus_amd import opus_sampling
+    g = load_golden("g5_sampling4d")
+    feats_cl = [dev(np.ascontiguousarray(g[f"feat_cf{i}"].transpose(0, 2, 3, 4, 1))) for i in range(4)]
+    out = opus_sampling.sampling_4d(
+        dev(g["sample_points"]), feats_cl, dev(g["scale_weights"]), dev(g["occ2img"]),
+        int(g["image_h"]), int(g["image_w"]), int(g["num_views"]))
+    assert_close(out.cpu().numpy(), g["out"], FWD_RTOL, "sampling_4d")
+
+
 # ---------------------------------------------------------------- full-size properties
 def _device_case(B, Q, P, seed, levels=REAL_LEVELS, N=6, C=64):
     gen = torch.Generator(device="cuda").manual_seed(seed)

@@ -1,0 +1,132 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports what the header declares,
+argument validation returns before any launch, the host mirror of the reference interface
+behaves like the reference's, and the caller restatement reproduces the golden packing."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FWD_RTOL, assert_close, golden_feats, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from opus_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "opus_msmv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(opus_msmv_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from opus_amd import _lib
+    declared = header_functions()
+    assert declared == sorted(_lib.SYMBOLS), "ctypes table and header disagree"
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.opus_msmv_version() == 100
+    assert lib.opus_msmv_strerror(0) == b"ok"
+    assert b"num_point exceed limits" in lib.opus_msmv_strerror(-2)
+    assert lib.opus_msmv_strerror(-99) == b"unknown error code"
+
+
+def test_argument_validation_returns_before_any_launch(lib):
+    from opus_amd import _lib
+    null = ctypes.c_void_p(0)
+    hw = _lib.int_array([4, 4])
+    ptrs = _lib.ptr_array([0])
+    fwd = lib.opus_msmv_forward
+    assert fwd(0, ptrs, hw, null, null, 1, 8, 6, 1, 1, null, null) == -1       # levels
+    assert fwd(9, ptrs, hw, null, null, 1, 8, 6, 1, 1, null, null) == -1
+    assert fwd(1, ptrs, hw, null, null, 1, 8, 6, 1, 33, null, null) == -2      # P > 32
+    assert fwd(1, ptrs, hw, null, null, 1, 8, 6, 1, 0, null, null) == -2
+    assert fwd(1, ptrs, hw, null, null, 1, 0, 6, 1, 1, null, null) == -3       # C == 0
+    assert fwd(1, ptrs, hw, null, null, -1, 8, 6, 1, 1, null, null) == -3
+    assert fwd(1, ptrs, _lib.int_array([0, 4]), null, null, 1, 8, 6, 1, 1, null, null) == -3
+    assert fwd(1, ptrs, hw, null, null, 1, 8, 6, 1, 1, null, null) == -4       # null data
+    assert fwd(1, ptrs, hw, null, null, 1 << 20, 64, 6, 1 << 10, 32, null, null) == -5
+    assert fwd(1, ptrs, hw, null, null, 0, 8, 6, 5, 1, null, null) == 0        # empty batch
+    assert fwd(1, ptrs, hw, null, null, 3, 8, 6, 0, 1, null, null) == 0        # no queries
+    assert lib.opus_msmv_forward_ex(1, ptrs, hw, null, null, 1, 8, 6, 1, 1, null, 0x80, null) == -7
+    bwd = lib.opus_msmv_backward
+    args = (1, null, ptrs, hw, null, null, 1, 8, 6, 1, 1, ptrs, null, null, null, 0)
+    assert bwd(*args, 3, null) == -7                                           # unknown algorithm
+    assert bwd(*args, 0x12, null) == -7                                        # accumulate + owner
+    assert bwd(*args, 0x101, null) == -7                                       # stage bits need owner
+    assert bwd(*args, 1, null) == -4                                           # null data
+    # workspace: none for the atomic algorithm, header + 32 B per point for the owner one
+    ws = lib.opus_msmv_backward_workspace_bytes
+    assert ws(4, 32, 64, 6, 4800, 2, 1) == 0
+    assert ws(4, 32, 8, 6, 4800, 2, 0) == 0                                    # C != 64 -> atomic
+    n = ws(4, 32, 64, 6, 4800, 2, 0)
+    assert n >= 32 * 4800 * 2 * 32 and n < 32 * 4800 * 2 * 32 + (1 << 20)
+
+
+def test_wrapper_mirrors_reference_names_and_checks():
+    from opus_amd.csrc import wrapper
+    for name in ("msmv_sampling", "msmv_sampling_pytorch", "MSMVSamplingC2345",
+                 "MSMVSamplingC23456", "MSMV_CUDA"):
+        assert hasattr(wrapper, name)
+    assert wrapper.MSMV_CUDA is True
+    g = load_golden("g1_tiny4")
+    feats = [torch.from_numpy(f) for f in golden_feats(g)]
+    loc, w = torch.from_numpy(g["loc"]), torch.from_numpy(g["w"])
+    # CPU tensors are rejected with the reference's message (msmv_sampling.cpp:113), never
+    # routed to a fallback
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        wrapper.msmv_sampling(feats, loc, w)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        wrapper.msmv_sampling([feats[0].transpose(2, 3)] + feats[1:], loc, w)
+
+
+def test_msmv_sampling_pytorch_matches_golden():
+    """The channel-first grid_sample formulation kept for API parity equals the reference's."""
+    from opus_amd.csrc import wrapper
+    for name in ("g1_tiny4", "g3_tiny5"):
+        g = load_golden(name)
+        feats_cf = [torch.from_numpy(f).permute(0, 4, 1, 2, 3).contiguous() for f in golden_feats(g)]
+        out = wrapper.msmv_sampling_pytorch(feats_cf, torch.from_numpy(g["loc"]), torch.from_numpy(g["w"]))
+        assert_close(out.numpy(), g["out"], 1e-6, f"{name} msmv_sampling_pytorch")
+
+
+def test_sampling_4d_packing_matches_golden(oracle):
+    """project_and_pack / unpack reproduce what the reference's sampling_4d hands to and takes
+    from the op (incl. first-valid-camera selection and the (B,T,G) / (B,G,T) packing)."""
+    from opus_amd import opus_sampling
+    g = load_golden("g5_sampling4d")
+    pts = torch.from_numpy(g["sample_points"])
+    B, Q, T, G, P, _ = pts.shape
+    loc, w = opus_sampling.project_and_pack(
+        pts, torch.from_numpy(g["scale_weights"]), torch.from_numpy(g["occ2img"]),
+        int(g["image_h"]), int(g["image_w"]), int(g["num_views"]))
+    assert loc.shape == g["op_loc"].shape and w.shape == g["op_w"].shape
+    # the selected camera must agree exactly; projected coordinates to float rounding
+    assert np.array_equal(loc[..., 2].numpy(), g["op_loc"][..., 2])
+    assert_close(loc.numpy(), g["op_loc"], 1e-6, "packed locations")
+    assert np.array_equal(w.numpy(), g["op_w"])
+    # op (oracle on channel-last features) + unpack == the reference's final output
+    feats_cl = [np.ascontiguousarray(g[f"feat_cf{i}"].transpose(0, 2, 3, 4, 1)) for i in range(4)]
+    op_out = oracle.forward(feats_cl, g["op_loc"], g["op_w"])
+    final = opus_sampling.unpack(torch.from_numpy(op_out), B, T, G)
+    assert_close(final.numpy(), g["out"], FWD_RTOL, "sampling_4d output")
+
+
+def test_relayout_features_matches_decoder_convention():
+    from opus_amd import opus_sampling
+    B, T, N, G, C, H, W = 2, 3, 2, 2, 4, 3, 5
+    feat = torch.arange(B * T * N * G * C * H * W, dtype=torch.float32).reshape(B, T * N, G * C, H, W)
+    out = opus_sampling.relayout_features([feat], T, N, G)[0]
+    assert out.shape == (B * T * G, N, H, W, C) and out.is_contiguous()
+    b, t, g, n, c, h, w = 1, 2, 1, 1, 3, 2, 4
+    assert out[(b * T + t) * G + g, n, h, w, c] == feat[b, t * N + n, g * C + c, h, w]
