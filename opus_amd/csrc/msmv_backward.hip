@@ -105,19 +105,29 @@ constexpr int BIN_PER_VIEW = BIN_YB * BIN_XB;
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_KEYS = 2048;       // N * BIN_PER_VIEW must not exceed this
 
-// workspace layout: [ offsets: B * (keys+1) ints, padded to 256 B ][ entries: npts * 32 B ]
+// workspace layout:
+//   [ counts: B*keys ints ][ cursors: B*keys ints ]   cleared by a memset node every call
+//   [ offsets: B*(keys+1) ints ]  (padded to 256 B)   exclusive prefix of the counts per batch
+//   [ entries: npts * 32 B ]
 // entries of batch b occupy [b*QP, b*QP + offsets[b][keys]), sorted by
-// key = (view*BIN_YB + yband)*BIN_XB + xband; offsets[b][k] is the exclusive prefix of the
-// key counts of batch b.
+// key = (view*BIN_YB + yband)*BIN_XB + xband (order inside a key is arbitrary).
 struct OwnerWs {
+    int *counts;
+    int *cursors;
     int *offsets;
     BinEntry *entries;
     int keys;             // N * BIN_PER_VIEW
+    int chunks;           // binning workgroups per batch slab
 };
+
+__host__ __device__ inline size_t owner_ws_clear_bytes(int B, int N)
+{
+    return (size_t)B * N * BIN_PER_VIEW * 2 * sizeof(int);
+}
 
 __host__ __device__ inline size_t owner_ws_header_bytes(int B, int N)
 {
-    const size_t h = (size_t)B * (N * BIN_PER_VIEW + 1) * sizeof(int);
+    const size_t h = owner_ws_clear_bytes(B, N) + (size_t)B * (N * BIN_PER_VIEW + 1) * sizeof(int);
     return (h + 255) & ~(size_t)255;
 }
 
@@ -147,64 +157,104 @@ __device__ __forceinline__ void msmv_band_range(int lo, int hi, int size, int &b
     }
 }
 
-// One workgroup per batch slab: LDS histogram over (view, yband, xband), exclusive scan,
-// then a second sweep that writes each point's entry into its key's segment.
+__device__ __forceinline__ int msmv_bin_key(const float *lp, int N)
+{
+    const int view = msmv_view_of(lp[2], N);
+    return view < 0 ? -1 : (view * BIN_YB + msmv_band_of<BIN_YB>(lp[1])) * BIN_XB + msmv_band_of<BIN_XB>(lp[0]);
+}
+
+// Counting sort of the points of every batch slab by key, in two short launches with one
+// point per thread and BIN_THREADS points per workgroup.
+// Pass 1: per-workgroup LDS histogram, then one global add per non-empty key.
 __global__ void __launch_bounds__(BIN_THREADS)
-msmv_bin_sort(const MsmvArgs a, OwnerWs ws)
+msmv_bin_count(const MsmvArgs a, OwnerWs ws)
 {
     __shared__ int hist[BIN_MAX_KEYS];
-    __shared__ int scan[2][BIN_MAX_KEYS];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x / ws.chunks, i = (blockIdx.x % ws.chunks) * BIN_THREADS + tid;
     const int keys = ws.keys;
-    const size_t pt0 = (size_t)b * a.qp;
-
     for (int k = tid; k < keys; k += BIN_THREADS)
         hist[k] = 0;
     __syncthreads();
-    for (int i = tid; i < a.qp; i += BIN_THREADS) {
-        const float *lp = a.loc + (pt0 + i) * 3;
-        const int view = msmv_view_of(lp[2], a.N);
-        if (view >= 0)
-            atomicAdd(&hist[(view * BIN_YB + msmv_band_of<BIN_YB>(lp[1])) * BIN_XB + msmv_band_of<BIN_XB>(lp[0])], 1);
+    if (i < a.qp) {
+        const int key = msmv_bin_key(a.loc + ((size_t)b * a.qp + i) * 3, a.N);
+        if (key >= 0)
+            atomicAdd(&hist[key], 1);
     }
     __syncthreads();
-    // inclusive Hillis-Steele scan of hist (keys <= 2048: at most 11 steps)
-    int cur = 0;
     for (int k = tid; k < keys; k += BIN_THREADS)
-        scan[0][k] = hist[k];
+        if (hist[k])
+            atomicAdd(ws.counts + (size_t)b * keys + k, hist[k]);
+}
+
+// Pass 2: every workgroup rebuilds the slab's exclusive prefix from the global counts,
+// claims a range per key with one global add, and places its points.
+__global__ void __launch_bounds__(BIN_THREADS)
+msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
+{
+    __shared__ int hist[BIN_MAX_KEYS];        // local counts, then the claimed base per key
+    __shared__ int scan[2][BIN_MAX_KEYS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / ws.chunks, chunk = blockIdx.x % ws.chunks;
+    const int i = chunk * BIN_THREADS + tid;
+    const int keys = ws.keys;
+    const size_t pt = (size_t)b * a.qp + i;
+
+    for (int k = tid; k < keys; k += BIN_THREADS) {
+        hist[k] = 0;
+        scan[0][k] = ws.counts[(size_t)b * keys + k];
+    }
     __syncthreads();
+    int key = -1, rank = 0;
+    float x = 0.f, y = 0.f;
+    if (i < a.qp) {
+        const float *lp = a.loc + pt * 3;
+        x = lp[0];
+        y = lp[1];
+        key = msmv_bin_key(lp, a.N);
+        if (key >= 0)
+            rank = atomicAdd(&hist[key], 1);
+    }
+    // inclusive Hillis-Steele scan of the slab's counts (keys <= 2048: at most 11 steps)
+    int cur = 0;
     for (int d = 1; d < keys; d <<= 1) {
+        __syncthreads();
         for (int k = tid; k < keys; k += BIN_THREADS)
             scan[cur ^ 1][k] = scan[cur][k] + (k >= d ? scan[cur][k - d] : 0);
         cur ^= 1;
-        __syncthreads();
-    }
-    int *off = ws.offsets + (size_t)b * (keys + 1);
-    for (int k = tid; k < keys; k += BIN_THREADS) {
-        const int excl = scan[cur][k] - hist[k];
-        off[k] = excl;
-        hist[k] = excl;                    // becomes the fill cursor
-        if (k == keys - 1)
-            off[keys] = scan[cur][k];
     }
     __syncthreads();
-    BinEntry *dst = ws.entries + pt0;
-    for (int i = tid; i < a.qp; i += BIN_THREADS) {
-        const float *lp = a.loc + (pt0 + i) * 3;
-        const float x = lp[0], y = lp[1];
-        const int view = msmv_view_of(lp[2], a.N);
-        if (view >= 0) {
-            const int slot = atomicAdd(&hist[(view * BIN_YB + msmv_band_of<BIN_YB>(y)) * BIN_XB + msmv_band_of<BIN_XB>(x)], 1);
-            const float *wp = a.w + (pt0 + i) * a.L;
-            float wv[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-                wv[k] = k < a.L ? wp[k] : 0.f;
-            float4 *e = reinterpret_cast<float4 *>(dst + slot);
-            e[0] = make_float4(__int_as_float((int)(pt0 + i)), x, y, wv[0]);
-            e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
+    for (int k = tid; k < keys; k += BIN_THREADS) {
+        const int n = hist[k];
+        const int excl = scan[cur][k] - ws.counts[(size_t)b * keys + k];
+        hist[k] = excl + (n ? atomicAdd(ws.cursors + (size_t)b * keys + k, n) : 0);
+        if (chunk == 0) {
+            int *off = ws.offsets + (size_t)b * (keys + 1);
+            off[k] = excl;
+            if (k == keys - 1)
+                off[keys] = scan[cur][k];
         }
+    }
+    __syncthreads();
+    if (i < a.qp && key < 0) {
+        // a point without a valid view is in no bin: its gradients are zero, written here
+        // because the bin-ordered gather pass never sees it
+        float *dl = a.dloc + pt * 3;
+        dl[0] = 0.f; dl[1] = 0.f; dl[2] = 0.f;
+        for (int k = 0; k < a.L; ++k)
+            a.dw[pt * a.L + k] = 0.f;
+    }
+    if (key >= 0) {
+        const float *wp = a.w + pt * a.L;
+        float wv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            wv[k] = k < a.L ? wp[k] : 0.f;
+        if (a.L <= 4)
+            wv[4] = __int_as_float(key / BIN_PER_VIEW);     // the view, for the gather pass
+        float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + hist[key] + rank);
+        e[0] = make_float4(__int_as_float((int)pt), x, y, wv[0]);
+        e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
     }
 }
 
@@ -462,9 +512,12 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 constexpr int GAT_THREADS = 256;
 constexpr int GAT_GROUPS_PER_WAVE = 4;
 
-template <int NL, int PT>
+// SORTED: rows walk the bin entries (points of a slab ordered by view and image band) instead
+// of the points in input order, so that the rows a CU works on at one time touch
+// neighbouring pixels; location, weights (and the view for L <= 4) come from the entry.
+template <int NL, int PT, bool SORTED>
 __global__ void __launch_bounds__(GAT_THREADS)
-msmv_bwd_gather_c64(const MsmvArgs a)
+msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
 {
     const int lane = threadIdx.x & 63;
     const int sub = lane >> 4;
@@ -480,19 +533,43 @@ msmv_bwd_gather_c64(const MsmvArgs a)
         if (g >= ngroups)
             break;
         const int pt_raw = g * 4 + sub;
-        const bool act = pt_raw < a.npts;
-        const int pt = act ? pt_raw : a.npts - 1;
-
-        const float *lp = a.loc + (size_t)pt * 3;
-        const float lx = lp[0], ly = lp[1], lv = lp[2];
-        float wl[NL];
+        bool act = pt_raw < a.npts;
+        int pt = act ? pt_raw : a.npts - 1;
+        float lx, ly, wl[NL];
+        int view, b;
+        if constexpr (SORTED) {
+            // slot pt of the entry array: slab b holds offsets[b][keys] entries from b*QP on
+            b = msmv_batch_of(pt, a);
+            const int n_b = ws.offsets[(size_t)b * (ws.keys + 1) + ws.keys];
+            act = act && (pt - b * a.qp) < n_b;
+            const float4 *e = reinterpret_cast<const float4 *>(ws.entries + (act ? pt : b * a.qp));
+            const float4 e0 = e[0], e1 = e[1];
+            if (n_b == 0)
+                act = false;                 // (the entry read above is then stale but in bounds)
+            pt = act ? __float_as_int(e0.x) : a.npts - 1;
+            lx = e0.y;
+            ly = e0.z;
+            const float wv[5] = {e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-        for (int l = 0; l < NL; ++l)
-            wl[l] = a.w[(size_t)pt * NL + l];
-
-        const int view = msmv_view_of(lv, a.N);
+            for (int l = 0; l < NL; ++l)
+                wl[l] = wv[l];
+            if constexpr (NL <= 4)
+                view = __float_as_int(e1.w);
+            else
+                view = msmv_view_of(a.loc[(size_t)pt * 3 + 2], a.N);
+            if (!act)
+                view = -1;
+        } else {
+            const float *lp = a.loc + (size_t)pt * 3;
+            lx = lp[0];
+            ly = lp[1];
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                wl[l] = a.w[(size_t)pt * NL + l];
+            view = msmv_view_of(lp[2], a.N);
+            b = msmv_batch_of(pt, a);
+        }
         const bool view_ok = view >= 0;
-        const int b = msmv_batch_of(pt, a);
         const size_t slab = (size_t)b * a.N + (view_ok ? view : 0);
 
         MsmvTap tap[NL];
@@ -512,6 +589,25 @@ msmv_bwd_gather_c64(const MsmvArgs a)
         float4 gq;
         if constexpr (PT == 1) {
             gq = ld4(a.gout + (size_t)pt * 64 + l16 * 4);
+        } else if constexpr (SORTED && PT == 2) {
+            // rows no longer hold the p = 0,1 pair of one query: fetch the row's 4 channels x 2 p
+            const float4 *gp = reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 1) * 64 + l16 * 4) * 2);
+            const float4 A = gp[0], B = gp[1];
+            const bool odd = pt & 1;
+            gq.x = odd ? A.y : A.x;
+            gq.y = odd ? A.w : A.z;
+            gq.z = odd ? B.y : B.x;
+            gq.w = odd ? B.w : B.z;
+        } else if constexpr (SORTED && PT == 4) {
+            const float4 *gp = reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 2) * 64 + l16 * 4) * 4);
+            const float4 A = gp[0], B = gp[1], C = gp[2], D = gp[3];
+            const bool p1 = pt & 1, p2 = pt & 2;
+#define MSMV_PICK(V) (p2 ? (p1 ? (V).w : (V).z) : (p1 ? (V).y : (V).x))
+            gq.x = MSMV_PICK(A);
+            gq.y = MSMV_PICK(B);
+            gq.z = MSMV_PICK(C);
+            gq.w = MSMV_PICK(D);
+#undef MSMV_PICK
         } else if constexpr (PT == 2) {
             const bool odd = sub & 1;
             const float4 o = ld4(a.gout + ((size_t)(pt >> 1) * 64 + l16 * 4 + (odd ? 2 : 0)) * 2);
@@ -571,16 +667,17 @@ msmv_bwd_gather_c64(const MsmvArgs a)
 }
 
 template <int NL>
-hipError_t launch_gather(const MsmvArgs &a, hipStream_t s)
+hipError_t launch_gather(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
 {
     const int ngroups = (a.npts + 3) / 4;
     const int per_block = (GAT_THREADS / 64) * GAT_GROUPS_PER_WAVE;
     const int nblk = (ngroups + per_block - 1) / per_block;
     switch (a.P) {
-    case 1: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 1>), dim3(nblk), dim3(GAT_THREADS), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 2>), dim3(nblk), dim3(GAT_THREADS), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 4>), dim3(nblk), dim3(GAT_THREADS), 0, s, a); break;
-    default: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 0>), dim3(nblk), dim3(GAT_THREADS), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 1, true>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
+    case 2: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 2, true>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
+    // P = 4 / other P: bin order would fetch 4x (Px) the gradient bytes per row; input order wins
+    case 4: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 4, false>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
+    default: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 0, false>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     }
     return hipGetLastError();
 }
@@ -626,13 +723,27 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
 hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages)
 {
     OwnerWs ws;
-    ws.offsets = reinterpret_cast<int *>(workspace);
-    ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N));
     ws.keys = a.N * BIN_PER_VIEW;
+    ws.chunks = (a.qp + BIN_THREADS - 1) / BIN_THREADS;
+    ws.counts = reinterpret_cast<int *>(workspace);
+    ws.cursors = ws.counts + (size_t)a.B * ws.keys;
+    ws.offsets = ws.cursors + (size_t)a.B * ws.keys;
+    ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N));
 
     hipError_t e;
     if (stages & 1) {
-        hipLaunchKernelGGL(msmv_bin_sort, dim3(a.B), dim3(BIN_THREADS), 0, s, a, ws);
+        if ((e = hipMemsetAsync(workspace, 0, owner_ws_clear_bytes(a.B, a.N), s)) != hipSuccess)
+            return e;
+        if (ws.chunks > 0) {
+            const dim3 grid((unsigned)(a.B * ws.chunks)), block(BIN_THREADS);
+            hipLaunchKernelGGL(msmv_bin_count, grid, block, 0, s, a, ws);
+            hipLaunchKernelGGL(msmv_bin_fill, grid, block, 0, s, a, ws);
+        } else {
+            // no queries: the offsets must still read as "every bin empty"
+            e = hipMemsetAsync(ws.offsets, 0, (size_t)a.B * (ws.keys + 1) * sizeof(int), s);
+            if (e != hipSuccess)
+                return e;
+        }
         if ((e = hipGetLastError()) != hipSuccess)
             return e;
     }
@@ -656,6 +767,6 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     if ((e = hipGetLastError()) != hipSuccess)
         return e;
     if (a.npts > 0 && (stages & 4))
-        return a.L == 4 ? launch_gather<4>(a, s) : launch_gather<5>(a, s);
+        return a.L == 4 ? launch_gather<4>(a, ws, s) : launch_gather<5>(a, ws, s);
     return hipSuccess;
 }

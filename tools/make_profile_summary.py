@@ -26,7 +26,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("msmv_fwd_c64", "msmv_bwd_owner_dfeat", "msmv_bwd_gather_c64", "msmv_bin_sort",
+    for k in ("msmv_fwd_c64", "msmv_bwd_owner_dfeat", "msmv_bwd_gather_c64", "msmv_bin_count", "msmv_bin_fill",
               "msmv_bwd_atomic", "msmv_fwd_generic", "calib_gather"):
         if k in name:
             return k
