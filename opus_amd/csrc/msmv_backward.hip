@@ -269,11 +269,15 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 // vector, then four read-modify-writes issued together (the corners of a point are distinct
 // pixels).  A corner outside the run is redirected, with weight 0, to a spare pixel slot
 // behind the run, which keeps the hit loop free of branches and of per-corner LDS waits.
+// The kernel is instruction-issue bound (scalar unit first), so the lanes that find hits
+// write 48-byte records into a small per-wave LDS queue and the wave then walks the queue
+// with uniform LDS reads: no per-hit mask arithmetic or v_readlane chains.
 constexpr int SUB_PIX = 22;              // pixels per wave: (22 + 1 spare) * 256 B = 5.75 KiB of LDS
 constexpr int OWN_WAVES = 8;
 constexpr int OWN_THREADS = OWN_WAVES * 64;
 constexpr int TILE_PIX = SUB_PIX * OWN_WAVES;   // 176 pixels, 46 KiB of LDS per workgroup, 3 workgroups per CU
-constexpr int OWN_BATCH = 8;             // hits whose gradient vectors are in flight together
+constexpr int OWN_QCAP = 16;             // hit records a wave queues in LDS before applying them
+constexpr int OWN_DEPTH = 2;             // records per group; two groups' gradient loads are in flight
 
 struct OwnerGeom {
     int tiles_per_level[MSMV_MAX_LEVELS];   // workgroups per (batch, view) slab of the level
@@ -324,20 +328,23 @@ __device__ __forceinline__ float msmv_select_grad(const GradRaw<PT> &r, int pt)
 struct OwnHit {
     int pt;
     bool hit;                        // at least one corner lies in the run
-    unsigned co12, co34;             // LDS byte offsets of the corners' pixels, two 16-bit fields each
+    unsigned co1, co2, co3, co4;     // LDS byte offsets of the corners' pixels (SPARE if outside the run)
     float cw1, cw2, cw3, cw4;        // corner weight * scale weight (0 for a corner outside the run)
 };
 
 template <int PT>
-__global__ void __launch_bounds__(OWN_THREADS)
+__global__ void __launch_bounds__(OWN_THREADS, 6)   // 3 workgroups per CU = 6 waves per SIMD: <= 80 VGPRs
 msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 {
-    constexpr int BATCH = OWN_BATCH;
-    __shared__ float4 tile_all[OWN_WAVES][(SUB_PIX + 1) * 16];
+    constexpr int D = PT == 4 ? 1 : OWN_DEPTH;     // P = 4 fetches 16 B per lane and record: keep registers <= 80
+    static_assert(OWN_QCAP % OWN_DEPTH == 0 && OWN_QCAP <= 64, "queue is read in whole groups");
+    // per wave: the run (+ 1 spare pixel), then the hit queue (3 float4 per record)
+    __shared__ float4 tile_all[OWN_WAVES][(SUB_PIX + 1) * 16 + OWN_QCAP * 3];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *tile = tile_all[wave];
+    float4 *queue = tile + (SUB_PIX + 1) * 16;
     char *tileb = reinterpret_cast<char *>(tile) + lane * 4;    // this lane's channel column
     constexpr unsigned SPARE = SUB_PIX * 256;                   // byte offset of the spare pixel
 
@@ -426,8 +433,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
         const unsigned b2 = in2 ? (unsigned)(t.o2 - s0) * 256u : SPARE;
         const unsigned b3 = in3 ? (unsigned)(t.o3 - s0) * 256u : SPARE;
         const unsigned b4 = in4 ? (unsigned)(t.o4 - s0) * 256u : SPARE;
-        h.co12 = b1 | (b2 << 16);
-        h.co34 = b3 | (b4 << 16);
+        h.co1 = b1; h.co2 = b2; h.co3 = b3; h.co4 = b4;
         h.cw1 = in1 ? t.w1 * wl : 0.f;
         h.cw2 = in2 ? t.w2 * wl : 0.f;
         h.cw3 = in3 ? t.w3 * wl : 0.f;
@@ -449,49 +455,89 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 
             unsigned long long hits = __ballot(h.hit);
 #ifdef MSMV_ABL_NOHITS
-            asm volatile("" ::"v"(h.co12), "v"(h.co34), "v"(h.cw1), "v"(h.cw2), "v"(h.cw3), "v"(h.cw4));
+            asm volatile("" ::"v"(h.co1), "v"(h.co2), "v"(h.co3), "v"(h.co4), "v"(h.cw1), "v"(h.cw2), "v"(h.cw3), "v"(h.cw4));
             hits = 0;
 #endif
-            while (hits) {
-                int j[BATCH], hpt[BATCH];
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    j[u] = hits ? __ffsll((long long)hits) - 1 : -1;
-                    hits &= hits - 1;                      // 0 stays 0
+            const int nh = __popcll(hits);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
+            for (int qbase = 0; qbase < nh; qbase += OWN_QCAP) {
+                // every slot first gets a harmless record (a valid point, never applied), then
+                // hit lanes qbase .. qbase+QCAP-1 (in lane order) overwrite theirs: the groups
+                // below can then fetch whole groups without a branch around the loads
+                if (lane < OWN_QCAP)
+                    queue[lane * 3] = make_float4(__int_as_float(h.pt), 0.f, 0.f, 0.f);
+                const unsigned slot = (unsigned)(rank - qbase);
+                if (h.hit && slot < (unsigned)OWN_QCAP) {
+                    float4 *q = queue + slot * 3;
+                    q[0] = make_float4(__int_as_float(h.pt), h.cw1, h.cw2, h.cw3);
+                    q[1] = make_float4(h.cw4, 0.f, 0.f, 0.f);
+                    q[2] = make_float4(__uint_as_float(h.co1), __uint_as_float(h.co2),
+                                       __uint_as_float(h.co3), __uint_as_float(h.co4));
                 }
-                GradRaw<PT> gv[BATCH];
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    // an empty slot re-reads the first hit's vector: no branch around the loads
-                    hpt[u] = __builtin_amdgcn_readlane(h.pt, j[u] >= 0 ? j[u] : j[0]);
-                    gv[u] = msmv_load_grad<PT>(a, hpt[u], lane);
+                const int cnt = min(OWN_QCAP, nh - qbase);
+                const int ngroups = (cnt + D - 1) / D;
+
+                // Two register sets (A, B) hold one group of D records each; the loads of
+                // group g+1 are issued before group g is applied, and every path is
+                // straight-line so that the compiler's counted waits leave them in flight.
+                float4 a_k[D], a_o[D], b_k[D], b_o[D];
+                float a_k4[D], b_k4[D];
+                int a_pt[D], b_pt[D];
+                GradRaw<PT> a_g[D], b_g[D];
+#define MSMV_OWN_LOAD(X, G)                                                                   \
+                _Pragma("unroll") for (int u = 0; u < D; ++u) {                              \
+                    const float4 *q = queue + ((G) * D + u) * 3;                             \
+                    X##_k[u] = q[0];                                                          \
+                    X##_pt[u] = __builtin_amdgcn_readfirstlane(__float_as_int(X##_k[u].x));  \
+                    X##_g[u] = msmv_load_grad<PT>(a, X##_pt[u], lane);                       \
+                    X##_k4[u] = q[1].x;                                                       \
+                    X##_o[u] = q[2];                                                          \
                 }
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    if (j[u] >= 0) {
-                        const int J = j[u];
-                        const float gu = msmv_select_grad<PT>(gv[u], hpt[u]);
-                        const unsigned o12 = __builtin_amdgcn_readlane(h.co12, J), o34 = __builtin_amdgcn_readlane(h.co34, J);
-                        const float k1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw1), J));
-                        const float k2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw2), J));
-                        const float k3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw3), J));
-                        const float k4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.cw4), J));
 #ifdef MSMV_ABL_NORMW
-                        asm volatile("" ::"s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(o12), "s"(o34), "v"(gu));
+#define MSMV_OWN_RMW(X, u) asm volatile("" ::"v"(X##_k[u].y), "v"(X##_k[u].z), "v"(X##_k[u].w), "v"(X##_k4[u]), "v"(X##_o[u].x), "v"(X##_o[u].y), "v"(X##_o[u].z), "v"(X##_o[u].w), "v"(gu));
 #else
-                        float *p1 = reinterpret_cast<float *>(tileb + (o12 & 0xFFFFu));
-                        float *p2 = reinterpret_cast<float *>(tileb + (o12 >> 16));
-                        float *p3 = reinterpret_cast<float *>(tileb + (o34 & 0xFFFFu));
-                        float *p4 = reinterpret_cast<float *>(tileb + (o34 >> 16));
-                        // read all four, then write all four: in-run corners are distinct pixels
-                        const float v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;
-                        *p1 = v1 + k1 * gu;
-                        *p2 = v2 + k2 * gu;
-                        *p3 = v3 + k3 * gu;
-                        *p4 = v4 + k4 * gu;
+#define MSMV_OWN_RMW(X, u)                                                                    \
+                        float *p1 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].x)); \
+                        float *p2 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].y)); \
+                        float *p3 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].z)); \
+                        float *p4 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].w)); \
+                        /* read all four, then write all four: in-run corners are distinct pixels */ \
+                        const float v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;                  \
+                        *p1 = v1 + X##_k[u].y * gu;                                           \
+                        *p2 = v2 + X##_k[u].z * gu;                                           \
+                        *p3 = v3 + X##_k[u].w * gu;                                           \
+                        *p4 = v4 + X##_k4[u] * gu;
 #endif
-                    }
+#define MSMV_OWN_APPLY(X, G)                                                                  \
+                _Pragma("unroll") for (int u = 0; u < D; ++u) {                              \
+                    if ((G) * D + u < cnt) {                                                  \
+                        const float gu = msmv_select_grad<PT>(X##_g[u], X##_pt[u]);          \
+                        MSMV_OWN_RMW(X, u)                                                    \
+                    }                                                                         \
                 }
+                MSMV_OWN_LOAD(a, 0)
+                for (int g = 0;;) {
+                    if (g + 1 < ngroups) {
+                        MSMV_OWN_LOAD(b, g + 1)
+                        MSMV_OWN_APPLY(a, g)
+                    } else {
+                        MSMV_OWN_APPLY(a, g)
+                        break;
+                    }
+                    ++g;
+                    if (g + 1 < ngroups) {
+                        MSMV_OWN_LOAD(a, g + 1)
+                        MSMV_OWN_APPLY(b, g)
+                    } else {
+                        MSMV_OWN_APPLY(b, g)
+                        break;
+                    }
+                    ++g;
+                }
+#undef MSMV_OWN_LOAD
+#undef MSMV_OWN_RMW
+#undef MSMV_OWN_APPLY
             }
         }
     }
