@@ -277,7 +277,10 @@ constexpr int OWN_WAVES = 8;
 constexpr int OWN_THREADS = OWN_WAVES * 64;
 constexpr int TILE_PIX = SUB_PIX * OWN_WAVES;   // 176 pixels, 46 KiB of LDS per workgroup, 3 workgroups per CU
 constexpr int OWN_QCAP = 16;             // hit records a wave queues in LDS before applying them
-constexpr int OWN_DEPTH = 2;             // records per group; two groups' gradient loads are in flight
+#ifndef MSMV_OWN_DEPTH
+#define MSMV_OWN_DEPTH 2
+#endif
+constexpr int OWN_DEPTH = MSMV_OWN_DEPTH;             // records per group; two groups' gradient loads are in flight
 
 struct OwnerGeom {
     int tiles_per_level[MSMV_MAX_LEVELS];   // workgroups per (batch, view) slab of the level
@@ -556,7 +559,10 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 // owner algorithm: d loc / d w gather (row of 16 lanes per point, like the forward)
 // ======================================================================================
 constexpr int GAT_THREADS = 256;
-constexpr int GAT_GROUPS_PER_WAVE = 4;
+#ifndef MSMV_GAT_GPW
+#define MSMV_GAT_GPW 2
+#endif
+constexpr int GAT_GROUPS_PER_WAVE = MSMV_GAT_GPW;
 
 // SORTED: rows walk the bin entries (points of a slab ordered by view and image band) instead
 // of the points in input order, so that the rows a CU works on at one time touch

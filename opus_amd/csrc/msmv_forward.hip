@@ -17,7 +17,10 @@
 namespace {
 
 constexpr int FWD_THREADS = 256;          // 4 waves
-constexpr int FWD_GROUPS_PER_WAVE = 4;    // 4-point groups each wave walks through
+#ifndef MSMV_FWD_GPW
+#define MSMV_FWD_GPW 1
+#endif
+constexpr int FWD_GROUPS_PER_WAVE = MSMV_FWD_GPW;    // 4-point groups each wave walks through
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
