@@ -264,13 +264,15 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 // LDS float atomics (ds_add_f32) cost ~190 LDS cycles per wave instruction on gfx950, so
 // no two waves ever share a pixel: each WAVE owns a run of SUB_PIX consecutive pixels of one
 // (batch, view, level) slab, keeps it in its private slice of LDS and updates it with plain
-// ds_read_b32 / ds_write_b32.  A hit (a point with at least one corner in the run) is
-// handled by the whole wave, lane = channel: one coalesced load of the point's gradient
-// vector, then four read-modify-writes issued together (the corners of a point are distinct
-// pixels).  A corner outside the run is redirected, with weight 0, to a spare pixel slot
-// behind the run, which keeps the hit loop free of branches and of per-corner LDS waits.
+// ds_read_b64 / ds_write_b64.  A hit (a point with at least one corner in the run) is
+// handled by the whole wave: each half of the wave takes one pixel of a horizontal corner
+// pair (32 lanes x 2 channels), so a pair costs one LDS read and one LDS write - the kernel
+// is LDS-issue bound, and 8-byte accesses move twice the bytes per LDS cycle of 4-byte ones.
+// A corner outside the run is redirected, with weight 0, to a spare pixel slot behind the
+// run, which keeps the hit loop free of per-corner branches (the corners of a point are
+// distinct pixels, so the read-modify-writes of one hit are independent).
 // The kernel is instruction-issue bound (scalar unit first), so the lanes that find hits
-// write 48-byte records into a small per-wave LDS queue and the wave then walks the queue
+// write 32-byte records into a small per-wave LDS queue and the wave then walks the queue
 // with uniform LDS reads: no per-hit mask arithmetic or v_readlane chains.
 constexpr int SUB_PIX = 22;              // pixels per wave: (22 + 1 spare) * 256 B = 5.75 KiB of LDS
 constexpr int OWN_WAVES = 8;
@@ -287,43 +289,60 @@ struct OwnerGeom {
     int tiles_per_b;                         // N * sum over levels
 };
 
-// grad_out[b,q,lane,p] of point pt for channel = lane.  grad_out is [B,Q,C,P]: for P in
-// {1,2,4} the P floats of a channel are fetched with one 4/8/16-byte load (a wave reads
-// 256*P contiguous bytes) and the point's p is picked afterwards; the generic form is a
-// P-strided dword load.
+// grad_out of point pt for this lane's two channels c0 = 2*(lane & 31), c0 + 1 (both halves of
+// the wave hold the same 64 channels: the halves work on the two pixels of a horizontal
+// corner pair).  grad_out is [B,Q,C,P]: for P in {1,2,4} the 2*P floats are contiguous and
+// fetched with 8/16-byte loads (a wave reads 256*P contiguous bytes); the generic form is a
+// P-strided dword gather.
 template <int PT>
-struct GradRaw { float v[PT == 0 ? 1 : PT]; };
+struct GradRaw { float v[PT == 0 ? 2 : 2 * PT]; };
 
 template <int PT>
-__device__ __forceinline__ GradRaw<PT> msmv_load_grad(const MsmvArgs &a, int pt, int lane)
+__device__ __forceinline__ GradRaw<PT> msmv_load_grad(const MsmvArgs &a, int pt, int l32)
 {
     GradRaw<PT> r;
     if constexpr (PT == 0) {
         const int bq = pt / a.P, p = pt - bq * a.P;
-        r.v[0] = a.gout[((size_t)bq * 64 + lane) * a.P + p];
+        const float *gp = a.gout + ((size_t)bq * 64 + l32 * 2) * a.P + p;
+        r.v[0] = gp[0];
+        r.v[1] = gp[(size_t)a.P];
     } else if constexpr (PT == 1) {
-        r.v[0] = a.gout[(size_t)pt * 64 + lane];
-    } else if constexpr (PT == 2) {
-        const float2 t = *reinterpret_cast<const float2 *>(a.gout + ((size_t)(pt >> 1) * 64 + lane) * 2);
+        const float2 t = *reinterpret_cast<const float2 *>(a.gout + (size_t)pt * 64 + l32 * 2);
         r.v[0] = t.x; r.v[1] = t.y;
-    } else {
-        const float4 t = *reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 2) * 64 + lane) * 4);
+    } else if constexpr (PT == 2) {
+        const float4 t = *reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 1) * 64 + l32 * 2) * 2);
         r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        const float4 *gp = reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 2) * 64 + l32 * 2) * 4);
+        const float4 t = gp[0], u = gp[1];
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+        r.v[4] = u.x; r.v[5] = u.y; r.v[6] = u.z; r.v[7] = u.w;
     }
     return r;
 }
 
 template <int PT>
-__device__ __forceinline__ float msmv_select_grad(const GradRaw<PT> &r, int pt)
+__device__ __forceinline__ float2 msmv_select_grad(const GradRaw<PT> &r, int pt)
 {
     if constexpr (PT == 0 || PT == 1) {
-        return r.v[0];
+        return make_float2(r.v[0], r.v[1]);
     } else if constexpr (PT == 2) {
-        const float x = r.v[0], y = r.v[1];
-        return (pt & 1) ? y : x;
+        // component-wise selects on named values: a select between aggregates by a scalar
+        // makes hipcc spill the array to scratch and index it
+        const float a0 = r.v[0], a1 = r.v[1], b0 = r.v[2], b1 = r.v[3];
+        const bool odd = pt & 1;
+        float2 g;
+        g.x = odd ? a1 : a0;
+        g.y = odd ? b1 : b0;
+        return g;
     } else {
-        const float x = r.v[0], y = r.v[1], z = r.v[2], w = r.v[3];
-        return (pt & 2) ? ((pt & 1) ? w : z) : ((pt & 1) ? y : x);
+        const bool p1 = pt & 1, p2 = pt & 2;
+        const float a0 = r.v[0], a1 = r.v[1], a2 = r.v[2], a3 = r.v[3];
+        const float b0 = r.v[4], b1 = r.v[5], b2 = r.v[6], b3 = r.v[7];
+        float2 g;
+        g.x = p2 ? (p1 ? a3 : a2) : (p1 ? a1 : a0);
+        g.y = p2 ? (p1 ? b3 : b2) : (p1 ? b1 : b0);
+        return g;
     }
 }
 
@@ -331,7 +350,7 @@ __device__ __forceinline__ float msmv_select_grad(const GradRaw<PT> &r, int pt)
 struct OwnHit {
     int pt;
     bool hit;                        // at least one corner lies in the run
-    unsigned co1, co2, co3, co4;     // LDS byte offsets of the corners' pixels (SPARE if outside the run)
+    unsigned co12, co34;             // LDS byte offsets of the corners' pixels, 16 bits each (SPARE if outside the run)
     float cw1, cw2, cw3, cw4;        // corner weight * scale weight (0 for a corner outside the run)
 };
 
@@ -341,14 +360,17 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 {
     constexpr int D = PT == 4 ? 1 : OWN_DEPTH;     // P = 4 fetches 16 B per lane and record: keep registers <= 80
     static_assert(OWN_QCAP % OWN_DEPTH == 0 && OWN_QCAP <= 64, "queue is read in whole groups");
-    // per wave: the run (+ 1 spare pixel), then the hit queue (3 float4 per record)
-    __shared__ float4 tile_all[OWN_WAVES][(SUB_PIX + 1) * 16 + OWN_QCAP * 3];
+    // per wave: the run (+ 1 spare pixel), then the hit queue (2 float4 per record)
+    __shared__ float4 tile_all[OWN_WAVES][(SUB_PIX + 1) * 16 + OWN_QCAP * 2];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *tile = tile_all[wave];
     float4 *queue = tile + (SUB_PIX + 1) * 16;
-    char *tileb = reinterpret_cast<char *>(tile) + lane * 4;    // this lane's channel column
+    const int l32 = lane & 31;
+    const unsigned half_shift = (lane >> 5) * 16;               // which 16-bit offset field this half uses
+    const bool upper = lane >= 32;
+    char *tileb = reinterpret_cast<char *>(tile) + l32 * 8;     // this lane's two channels inside a pixel
     constexpr unsigned SPARE = SUB_PIX * 256;                   // byte offset of the spare pixel
 
     // ---- which run of pixels: logical order [b][level, coarse first][view][tile][wave]
@@ -436,7 +458,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
         const unsigned b2 = in2 ? (unsigned)(t.o2 - s0) * 256u : SPARE;
         const unsigned b3 = in3 ? (unsigned)(t.o3 - s0) * 256u : SPARE;
         const unsigned b4 = in4 ? (unsigned)(t.o4 - s0) * 256u : SPARE;
-        h.co1 = b1; h.co2 = b2; h.co3 = b3; h.co4 = b4;
+        h.co12 = b1 | (b2 << 16);
+        h.co34 = b3 | (b4 << 16);
         h.cw1 = in1 ? t.w1 * wl : 0.f;
         h.cw2 = in2 ? t.w2 * wl : 0.f;
         h.cw3 = in3 ? t.w3 * wl : 0.f;
@@ -458,7 +481,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 
             unsigned long long hits = __ballot(h.hit);
 #ifdef MSMV_ABL_NOHITS
-            asm volatile("" ::"v"(h.co1), "v"(h.co2), "v"(h.co3), "v"(h.co4), "v"(h.cw1), "v"(h.cw2), "v"(h.cw3), "v"(h.cw4));
+            asm volatile("" ::"v"(h.co12), "v"(h.co34), "v"(h.cw1), "v"(h.cw2), "v"(h.cw3), "v"(h.cw4));
             hits = 0;
 #endif
             const int nh = __popcll(hits);
@@ -469,14 +492,12 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 // hit lanes qbase .. qbase+QCAP-1 (in lane order) overwrite theirs: the groups
                 // below can then fetch whole groups without a branch around the loads
                 if (lane < OWN_QCAP)
-                    queue[lane * 3] = make_float4(__int_as_float(h.pt), 0.f, 0.f, 0.f);
+                    queue[lane * 2] = make_float4(__int_as_float(h.pt), 0.f, 0.f, 0.f);
                 const unsigned slot = (unsigned)(rank - qbase);
                 if (h.hit && slot < (unsigned)OWN_QCAP) {
-                    float4 *q = queue + slot * 3;
+                    float4 *q = queue + slot * 2;
                     q[0] = make_float4(__int_as_float(h.pt), h.cw1, h.cw2, h.cw3);
-                    q[1] = make_float4(h.cw4, 0.f, 0.f, 0.f);
-                    q[2] = make_float4(__uint_as_float(h.co1), __uint_as_float(h.co2),
-                                       __uint_as_float(h.co3), __uint_as_float(h.co4));
+                    q[1] = make_float4(h.cw4, __uint_as_float(h.co12), __uint_as_float(h.co34), 0.f);
                 }
                 const int cnt = min(OWN_QCAP, nh - qbase);
                 const int ngroups = (cnt + D - 1) / D;
@@ -484,38 +505,47 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 // Two register sets (A, B) hold one group of D records each; the loads of
                 // group g+1 are issued before group g is applied, and every path is
                 // straight-line so that the compiler's counted waits leave them in flight.
-                float4 a_k[D], a_o[D], b_k[D], b_o[D];
-                float a_k4[D], b_k4[D];
+                // Only the point index and the gradient vector are carried between the two
+                // phases; weights and offsets are re-read from the queue when applied.
                 int a_pt[D], b_pt[D];
                 GradRaw<PT> a_g[D], b_g[D];
+#ifdef MSMV_ABL_NOGLOAD
+                GradRaw<PT> fake_g;
+                for (int k = 0; k < (PT == 0 ? 2 : 2 * PT); ++k) fake_g.v[k] = (float)(lane + k);
+#define MSMV_OWN_GLOAD(PTX) fake_g
+#else
+#define MSMV_OWN_GLOAD(PTX) msmv_load_grad<PT>(a, PTX, l32)
+#endif
 #define MSMV_OWN_LOAD(X, G)                                                                   \
                 _Pragma("unroll") for (int u = 0; u < D; ++u) {                              \
-                    const float4 *q = queue + ((G) * D + u) * 3;                             \
-                    X##_k[u] = q[0];                                                          \
-                    X##_pt[u] = __builtin_amdgcn_readfirstlane(__float_as_int(X##_k[u].x));  \
-                    X##_g[u] = msmv_load_grad<PT>(a, X##_pt[u], lane);                       \
-                    X##_k4[u] = q[1].x;                                                       \
-                    X##_o[u] = q[2];                                                          \
+                    const float *q = reinterpret_cast<const float *>(queue + ((G) * D + u) * 2); \
+                    X##_pt[u] = __builtin_amdgcn_readfirstlane(__float_as_int(q[0]));        \
+                    X##_g[u] = MSMV_OWN_GLOAD(X##_pt[u]);                                    \
                 }
 #ifdef MSMV_ABL_NORMW
-#define MSMV_OWN_RMW(X, u) asm volatile("" ::"v"(X##_k[u].y), "v"(X##_k[u].z), "v"(X##_k[u].w), "v"(X##_k4[u]), "v"(X##_o[u].x), "v"(X##_o[u].y), "v"(X##_o[u].z), "v"(X##_o[u].w), "v"(gu));
+#define MSMV_OWN_RMW(X, u) asm volatile("" ::"v"(rk.y), "v"(rk.z), "v"(rk.w), "v"(ro.x), "v"(ro.y), "v"(ro.z), "v"(gu.x), "v"(gu.y));
 #else
 #define MSMV_OWN_RMW(X, u)                                                                    \
-                        float *p1 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].x)); \
-                        float *p2 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].y)); \
-                        float *p3 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].z)); \
-                        float *p4 = reinterpret_cast<float *>(tileb + __float_as_uint(X##_o[u].w)); \
-                        /* read all four, then write all four: in-run corners are distinct pixels */ \
-                        const float v1 = *p1, v2 = *p2, v3 = *p3, v4 = *p4;                  \
-                        *p1 = v1 + X##_k[u].y * gu;                                           \
-                        *p2 = v2 + X##_k[u].z * gu;                                           \
-                        *p3 = v3 + X##_k[u].w * gu;                                           \
-                        *p4 = v4 + X##_k4[u] * gu;
+                        /* lower half: corners 1 and 3, upper half: corners 2 and 4 */       \
+                        const float kt = upper ? rk.z : rk.y;                                 \
+                        const float kb = upper ? ro.x : rk.w;                                 \
+                        const unsigned ot = (__float_as_uint(ro.y) >> half_shift) & 0xFFFFu; \
+                        const unsigned ob = (__float_as_uint(ro.z) >> half_shift) & 0xFFFFu; \
+                        float2 *pt_ = reinterpret_cast<float2 *>(tileb + ot);                \
+                        float2 *pb_ = reinterpret_cast<float2 *>(tileb + ob);                \
+                        /* read both pairs, then write both: in-run corners are distinct pixels */ \
+                        float2 vt = *pt_, vb = *pb_;                                          \
+                        vt.x += kt * gu.x; vt.y += kt * gu.y;                                 \
+                        vb.x += kb * gu.x; vb.y += kb * gu.y;                                 \
+                        *pt_ = vt;                                                            \
+                        *pb_ = vb;
 #endif
 #define MSMV_OWN_APPLY(X, G)                                                                  \
                 _Pragma("unroll") for (int u = 0; u < D; ++u) {                              \
                     if ((G) * D + u < cnt) {                                                  \
-                        const float gu = msmv_select_grad<PT>(X##_g[u], X##_pt[u]);          \
+                        const float4 rk = queue[((G) * D + u) * 2];                          \
+                        const float4 ro = queue[((G) * D + u) * 2 + 1];                      \
+                        const float2 gu = msmv_select_grad<PT>(X##_g[u], X##_pt[u]);         \
                         MSMV_OWN_RMW(X, u)                                                    \
                     }                                                                         \
                 }
@@ -539,6 +569,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                     ++g;
                 }
 #undef MSMV_OWN_LOAD
+#undef MSMV_OWN_GLOAD
 #undef MSMV_OWN_RMW
 #undef MSMV_OWN_APPLY
             }
