@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libopus_msmv.so")
+# OPUS_MSMV_LIB points at another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("OPUS_MSMV_LIB") or os.path.join(_HERE, "csrc", "libopus_msmv.so")
 
 OK = 0
 BWD_AUTO, BWD_ATOMIC, BWD_OWNER = 0, 1, 2
