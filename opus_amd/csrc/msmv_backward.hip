@@ -14,12 +14,12 @@
 //              atomics per value); d feat uses fp32 global atomics, each wave instruction
 //              covering the 256 contiguous bytes of one corner.  Works for every shape.
 //              Bounded by the chip's float-atomic rate (~1.3 TB/s of added bytes).
-//  * owner   - no atomics and no clear of d feat: points are first binned by (batch, view);
-//              every run of TILE_PIX consecutive pixels of a (batch, view, level) slab is
-//              owned by one workgroup, which scans its bin, accumulates the contributions
-//              that land in its run in LDS (ds_add_f32) and then writes the run once with
-//              plain 16-byte stores (zeros included).  d loc / d w come from a separate
-//              gather kernel shaped like the forward (row of 16 lanes per point).  C == 64.
+//  * owner   - no atomics and no clear of d feat: points are first counting-sorted into bins
+//              by (batch, view, y-band, x-band); every 4x8-pixel patch of a (batch, view,
+//              level) slab is owned by one wave, which scans the bins that can reach it,
+//              accumulates the contributions in fp32 MFMA registers and stores the patch
+//              once (zeros included).  d loc / d w come from a separate gather kernel shaped
+//              like the forward (row of 16 lanes per point).  C == 64, L in {4, 5}.
 #include "msmv_common.h"
 #include "msmv_launch.h"
 
@@ -261,11 +261,11 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 // ======================================================================================
 // owner algorithm: d feat tiles
 // ======================================================================================
-// d feat of a run of 32 consecutive pixels of one (batch, view, level) slab is
+// d feat of a patch of PATCH_H x PATCH_W = 32 pixels of one (batch, view, level) slab is
 //     D[pixel i][channel c] = sum over hits h of  W[i][h] * G[h][c],
 // W[i][h] = corner weight * scale weight of the corner of point h that lands on pixel i (at
 // most four non-zeros per column), G[h] = the point's 64-channel gradient vector.  Each
-// WAVE owns one run and keeps D in registers as two 32x32 fp32 MFMA accumulators
+// WAVE owns one patch and keeps D in registers as two 32x32 fp32 MFMA accumulators
 // (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, K = 2 hits per instruction; tile 0 holds
 // the even channels, tile 1 the odd ones, so that a lane fetches its two channels of
 // grad_out with one vector load and stores them with one 8-byte store).  The dense product
@@ -274,19 +274,23 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 // read-modify-writes, were bound by VALU / scalar / LDS instruction issue (45 CU cycles per
 // hit), and LDS float atomics (ds_add_f32) cost ~190 LDS cycles per wave instruction.
 // No pixel is shared between waves, nothing is cleared, every d-feat byte is stored once.
+// The patch is 4 rows x 8 columns rather than 32 pixels of one row because a point's 2x2
+// footprint then falls into 1.4 patches on average instead of 2.1: a third fewer hits.
 //
 // A wave scans only the bins whose bands can reach its rows / columns; lanes that find a
-// hit (a point with a corner in the run) write a 32-byte record into a small per-wave LDS
+// hit (a point with a corner in the patch) write a 32-byte record into a small per-wave LDS
 // queue; the wave then consumes the queue two records at a time (one per half-wave).
-constexpr int SUB_PIX = 32;              // pixels per wave = M of the MFMA tile
-constexpr int OWN_WAVES = 8;
+constexpr int PATCH_H = 4, PATCH_W = 8;
+static_assert(PATCH_H * PATCH_W == 32, "a patch is the M = 32 dimension of the MFMA tile");
+constexpr int OWN_WAVES = 8;                     // patches per workgroup
 constexpr int OWN_THREADS = OWN_WAVES * 64;
-constexpr int TILE_PIX = SUB_PIX * OWN_WAVES;   // 256 pixels per workgroup
 constexpr int OWN_QCAP = 16;             // hit records a wave queues before consuming them
 constexpr int OWN_GROUP = 2;             // record pairs per group; two groups' gradient loads are in flight
 
 struct OwnerGeom {
     int tiles_per_level[MSMV_MAX_LEVELS];   // workgroups per (batch, view) slab of the level
+    int patch_cols[MSMV_MAX_LEVELS];        // patches per row of patches: ceil(W / PATCH_W)
+    int patches[MSMV_MAX_LEVELS];           // patches per slab: ceil(H / PATCH_H) * patch_cols
     int tiles_per_b;                         // N * sum over levels
 };
 
@@ -350,9 +354,9 @@ __device__ __forceinline__ float2 msmv_select_grad(const GradRaw<PT> &r, int pt)
 // What one lane knows about the bin entry it scanned (one point against this wave's run).
 struct OwnHit {
     int pt;
-    bool hit;                        // at least one corner lies in the run
-    unsigned pix;                    // pixel index inside the run of corners 1..4, 8 bits each (255 = outside)
-    float cw1, cw2, cw3, cw4;        // corner weight * scale weight (0 for a corner outside the run)
+    bool hit;                        // at least one corner lies in the patch
+    unsigned pix;                    // pixel index inside the patch of corners 1..4, 8 bits each (255 = outside)
+    float cw1, cw2, cw3, cw4;        // corner weight * scale weight (0 for a corner outside the patch)
 };
 
 template <int PT>
@@ -384,20 +388,20 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     const int tile_idx = id - view * geo.tiles_per_level[l];
     const int H = a.lvl[l].H, W = a.lvl[l].W;
     const int S = H * W;
-    const int s0 = tile_idx * TILE_PIX + wave * SUB_PIX;     // first pixel of this wave's run
-    const int npix = min(SUB_PIX, S - s0);
-    if (npix <= 0)
+    const int patch = tile_idx * OWN_WAVES + wave;           // this wave's patch, row-major
+    if (patch >= geo.patches[l])
         return;                                              // wave-uniform; no barriers below
+    const int prow = patch / geo.patch_cols[l];
+    const int r0 = prow * PATCH_H, c0 = (patch - prow * geo.patch_cols[l]) * PATCH_W;
+    const int nrow = min(PATCH_H, H - r0), ncol = min(PATCH_W, W - c0);
 
     msmv_f32x16 acc0 = {}, acc1 = {};                        // even / odd channels
 
-    // ---- the bins that can reach this run: one segment of the sorted entries per y-band
+    // ---- the bins that can reach this patch: one segment of the sorted entries per y-band
     // (all of them adjacent, i.e. one segment, when every x-band is wanted)
-    const int r0 = s0 / W, r1 = (s0 + npix - 1) / W;
-    int yb_lo, yb_hi, xb_lo = 0, xb_hi = BIN_XB - 1;
-    msmv_band_range<BIN_YB>(r0, r1, H, yb_lo, yb_hi);
-    if (r0 == r1)
-        msmv_band_range<BIN_XB>(s0 - r0 * W, s0 + npix - 1 - r0 * W, W, xb_lo, xb_hi);
+    int yb_lo, yb_hi, xb_lo, xb_hi;
+    msmv_band_range<BIN_YB>(r0, r0 + nrow - 1, H, yb_lo, yb_hi);
+    msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, xb_lo, xb_hi);
     const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
     const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB = 16
     const int *off = ws.offsets + (size_t)b * (ws.keys + 1) + view * BIN_PER_VIEW;
@@ -444,13 +448,17 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
         const bool valid = v0 + lane < total;
         h.pt = __float_as_int(e0.x);
         const MsmvTap t = msmv_make_tap(e0.y, e0.z, H, W, valid);
-        const bool in1 = t.c1 && (unsigned)(t.o1 - s0) < (unsigned)npix;
-        const bool in2 = t.c2 && (unsigned)(t.o2 - s0) < (unsigned)npix;
-        const bool in3 = t.c3 && (unsigned)(t.o3 - s0) < (unsigned)npix;
-        const bool in4 = t.c4 && (unsigned)(t.o4 - s0) < (unsigned)npix;
+        // corner rows / columns relative to the patch; the unsigned compares also reject the
+        // -1 row / column of a corner that is off the image (its c-flag is false anyway)
+        const unsigned dr0 = (unsigned)(t.h_low - r0), dr1 = (unsigned)(t.h_low + 1 - r0);
+        const unsigned dc0 = (unsigned)(t.w_low - c0), dc1 = (unsigned)(t.w_low + 1 - c0);
+        const bool rt = dr0 < (unsigned)nrow, rb = dr1 < (unsigned)nrow;
+        const bool cl = dc0 < (unsigned)ncol, cr = dc1 < (unsigned)ncol;
+        const bool in1 = t.c1 && rt && cl, in2 = t.c2 && rt && cr;
+        const bool in3 = t.c3 && rb && cl, in4 = t.c4 && rb && cr;
         h.hit = in1 || in2 || in3 || in4;
-        const unsigned p1 = in1 ? (unsigned)(t.o1 - s0) : 255u, p2 = in2 ? (unsigned)(t.o2 - s0) : 255u;
-        const unsigned p3 = in3 ? (unsigned)(t.o3 - s0) : 255u, p4 = in4 ? (unsigned)(t.o4 - s0) : 255u;
+        const unsigned p1 = in1 ? dr0 * PATCH_W + dc0 : 255u, p2 = in2 ? dr0 * PATCH_W + dc1 : 255u;
+        const unsigned p3 = in3 ? dr1 * PATCH_W + dc0 : 255u, p4 = in4 ? dr1 * PATCH_W + dc1 : 255u;
         h.pix = p1 | (p2 << 8) | (p3 << 16) | (p4 << 24);
         h.cw1 = in1 ? t.w1 * wl : 0.f;
         h.cw2 = in2 ? t.w2 * wl : 0.f;
@@ -554,20 +562,21 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
         }
     }
 
-    // ---- store the run once.  Accumulator register r of lane (half, l32) is pixel
-    // (r & 3) + 8 * (r >> 2) + 4 * half, channels 2*l32 (tile 0) and 2*l32 + 1 (tile 1): each
-    // half-wave stores one whole 256-byte pixel row per instruction.  (Exchanging registers
-    // between lane pairs to issue 16-byte stores instead measured 7 % slower: the two rows
-    // then interleave lane by lane.)
-    float *dst = a.lvl[l].dfeat + (((size_t)b * a.N + view) * (size_t)S + s0) * 64 + l32 * 2;
+    // ---- store the patch once.  Accumulator register r of lane (half, l32) is patch pixel
+    // i = (r & 3) + 8 * (r >> 2) + 4 * half, i.e. row i / PATCH_W, column i % PATCH_W, channels
+    // 2*l32 (tile 0) and 2*l32 + 1 (tile 1): each half-wave stores one whole 256-byte pixel
+    // per instruction.  (Exchanging registers between lane pairs to issue 16-byte stores
+    // instead measured 7 % slower: the two pixels then interleave lane by lane.)
+    float *dst = a.lvl[l].dfeat + (((size_t)b * a.N + view) * (size_t)S + (size_t)r0 * W + c0) * 64 + l32 * 2;
 #ifdef MSMV_ABL_NOSTORE
-    if (npix < 0)
+    if (nrow < 0)
 #endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (i < npix)
-            *reinterpret_cast<float2 *>(dst + (size_t)i * 64) = make_float2(acc0[r], acc1[r]);
+        const int pr = i / PATCH_W, pc = i % PATCH_W;
+        if (pr < nrow && pc < ncol)
+            *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) = make_float2(acc0[r], acc1[r]);
     }
 }
 
@@ -819,7 +828,9 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     OwnerGeom geo = {};
     int per_view = 0;
     for (int l = 0; l < a.L; ++l) {
-        geo.tiles_per_level[l] = (a.lvl[l].H * a.lvl[l].W + TILE_PIX - 1) / TILE_PIX;
+        geo.patch_cols[l] = (a.lvl[l].W + PATCH_W - 1) / PATCH_W;
+        geo.patches[l] = ((a.lvl[l].H + PATCH_H - 1) / PATCH_H) * geo.patch_cols[l];
+        geo.tiles_per_level[l] = (geo.patches[l] + OWN_WAVES - 1) / OWN_WAVES;
         per_view += geo.tiles_per_level[l];
     }
     geo.tiles_per_b = per_view * a.N;

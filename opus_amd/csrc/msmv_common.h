@@ -43,6 +43,7 @@ struct MsmvTap {
     float w1, w2, w3, w4;   // hh*hw, hh*lw, lh*hw, lh*lw  with invalid corners' weights as computed (not zeroed)
     float lh, lw, hh, hw;
     int o1, o2, o3, o4;     // pixel offsets (h*W + w) of the four corners, clamped into the slab
+    int h_low, w_low;       // row / column of corner 1 (may be -1)
     bool ok;                // level in range: -1 < h_im < H and -1 < w_im < W
     bool c1, c2, c3, c4;    // corner inside the image
 };
@@ -58,6 +59,8 @@ __device__ __forceinline__ MsmvTap msmv_make_tap(float loc_w, float loc_h, int H
     w_im = t.ok ? w_im : 0.f;
     const float hf = floorf(h_im), wf = floorf(w_im);
     const int h_low = (int)hf, w_low = (int)wf;
+    t.h_low = h_low;
+    t.w_low = w_low;
     t.lh = h_im - hf;
     t.lw = w_im - wf;
     t.hh = 1.f - t.lh;
