@@ -111,6 +111,47 @@ def test_forward_backward_match_oracle(wr, oracle, case):
     assert_close(out_generic, ref_out, FWD_RTOL, "forward [generic kernel]")
 
 
+def _check_all(wr, oracle, feats, loc, w, grad_out, algos=ALGOS):
+    ref_out = oracle.forward(feats, loc, w)
+    ref_df, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
+    for algo in algos:
+        out, dfeats, dloc, dw = run_hip(wr, feats, loc, w, grad_out, algo=algo)
+        assert_close(out, ref_out, FWD_RTOL, f"forward [{algo}]")
+        for i, d in enumerate(dfeats):
+            assert_close(d, ref_df[i], GRAD_RTOL, f"dfeat{i} [{algo}]")
+        assert_close(dloc, ref_dloc, GRAD_RTOL, f"dloc [{algo}]")
+        assert_close(dw, ref_dw, GRAD_RTOL, f"dw [{algo}]")
+
+
+def test_hot_spot_thousands_of_points_in_one_patch(wr, oracle):
+    """Every point lands in the same few pixels of one view: one bin holds all entries and
+    single patches receive thousands of hits (many scan chunks, many queue rounds)."""
+    feats, loc, w, grad_out = random_case(31, REAL_LEVELS, B=2, N=6, C=64, Q=1500, P=2, oob_frac=0)
+    rng = np.random.default_rng(5)
+    loc[..., 0] = 0.40 + 0.01 * rng.random(loc.shape[:-1])
+    loc[..., 1] = 0.70 + 0.01 * rng.random(loc.shape[:-1])
+    loc[..., 2] = 2 / 5
+    loc[1, :, :, 2] = (rng.integers(0, 2, loc.shape[1:3]) * 3) / 5      # slab 1: views 0 and 3 only
+    _check_all(wr, oracle, feats, loc, w, grad_out)
+
+
+def test_odd_level_sizes_and_partial_patches(wr, oracle):
+    levels = [(13, 31), (5, 7), (3, 9), (1, 1)]
+    for P in (1, 2, 4, 5):
+        feats, loc, w, grad_out = random_case(40 + P, levels, B=2, N=3, C=64, Q=40, P=P, oob_frac=0.3)
+        _check_all(wr, oracle, feats, loc, w, grad_out)
+
+
+def test_many_views_and_max_points(wr, oracle):
+    # 16 views is the most the owner algorithm's bin table holds; 17 must use the atomic one
+    feats, loc, w, grad_out = random_case(50, TINY_LEVELS, B=1, N=16, C=64, Q=30, P=32, oob_frac=0.2)
+    _check_all(wr, oracle, feats, loc, w, grad_out)
+    feats, loc, w, grad_out = random_case(51, TINY_LEVELS, B=1, N=17, C=64, Q=12, P=2, oob_frac=0.2)
+    _check_all(wr, oracle, feats, loc, w, grad_out, algos=["atomic", "auto"])
+    with pytest.raises(RuntimeError, match="algorithm"):
+        run_hip(wr, feats, loc, w, grad_out, algo="owner")
+
+
 def test_out_of_range_view_and_nan_location(wr, oracle):
     feats, loc, w, grad_out = random_case(5, REAL_LEVELS, B=1, N=6, C=64, Q=8, P=2, oob_frac=0)
     loc[0, 0, 0, 2] = 1.3
