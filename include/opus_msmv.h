@@ -120,6 +120,34 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
                        float *const *dfeats, float *dloc, float *dweights,
                        void *workspace, size_t workspace_bytes, int flags, void *stream);
 
+/*
+ * Caller-side fusion: everything sampling_4d does before it calls the op
+ * (models/opus_sampling.py:36-113), in one launch.
+ *   sample_points [B,Q,T,G,P,3] (metres), scale_weights [B,Q,G,T,P,L], occ2img [B,T*N,4,4]
+ *   -> loc [B*T*G,Q,P,3] = (u, v, view/(N-1)) of the first camera (of the point's frame) in
+ *      which the point is visible (z > eps, 0 < u,v < 1), camera 0 if none (opus_sampling.py:94);
+ *      weights [B*G*T,Q,P,L] = the scale weights re-packed.  Points are packed in (B,T,G)
+ *      order and weights in (B,G,T) order, as the reference does (opus_sampling.py:104-112).
+ * Requires N >= 2 (the reference divides by N-1, opus_sampling.py:101).
+ */
+int opus_msmv_project_pack(const float *sample_points, const float *scale_weights, const float *occ2img,
+                           int B, int Q, int T, int G, int P, int L, int N,
+                           float image_h, float image_w, float eps,
+                           float *loc, float *weights, void *stream);
+
+/*
+ * Backward of opus_msmv_project_pack: d sample_points [B,Q,T,G,P,3] from d loc (the view
+ * slot carries no gradient, nor do the visibility mask and the camera choice) through the
+ * chosen camera's projection, and d scale_weights [B,Q,G,T,P,L] = d weights un-packed.
+ * `loc` is the forward's output (it holds the chosen camera).  occ2img gets no gradient:
+ * it is built from image metadata in the reference (models/opus_transformer.py:105-110).
+ */
+int opus_msmv_project_pack_backward(const float *dloc, const float *dweights,
+                                    const float *sample_points, const float *occ2img, const float *loc,
+                                    int B, int Q, int T, int G, int P, int L, int N,
+                                    float image_h, float image_w, float eps,
+                                    float *dsample_points, float *dscale_weights, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,12 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "opus_msmv_project_pack": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
+        + [ctypes.c_float] * 3 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "opus_msmv_project_pack_backward": (ctypes.c_int, [
+        ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_float] * 3
+        + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 _lib = None

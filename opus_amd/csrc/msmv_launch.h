@@ -14,3 +14,14 @@ bool msmv_backward_owner_supported(const MsmvArgs &a);
 size_t msmv_backward_owner_workspace(int B, int N, int Q, int P);
 // stages: bit 0 = bin, bit 1 = d feat tiles, bit 2 = d loc / d w gather
 hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages);
+
+// Caller-side fusion (msmv_project.hip): projection + view selection + packing, and its backward.
+hipError_t msmv_launch_project_pack(const float *pts, const float *sw, const float *occ2img,
+                                    int B, int Q, int T, int G, int P, int L, int N,
+                                    float image_h, float image_w, float eps,
+                                    float *loc, float *w, hipStream_t s);
+hipError_t msmv_launch_project_pack_backward(const float *dloc, const float *dw, const float *pts,
+                                             const float *occ2img, const float *loc,
+                                             int B, int Q, int T, int G, int P, int L, int N,
+                                             float image_h, float image_w, float eps,
+                                             float *dpts, float *dsw, hipStream_t s);

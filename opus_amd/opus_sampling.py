@@ -17,8 +17,11 @@ Feature maps are expected in the layout the HIP op takes, [B*T*G, N, H, W, C] (c
 i.e. what the reference's decoder prepares when MSMV_CUDA is true
 (models/opus_transformer.py:119-121); ``relayout_features`` restates that step.
 """
+import ctypes
+
 import torch
 
+from . import _lib
 from .csrc.wrapper import msmv_sampling
 
 
@@ -38,8 +41,10 @@ def relayout_features(mlvl_feats, num_frames, num_views, num_groups):
     return out
 
 
-def project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
-    """Everything ``sampling_4d`` does before the op (opus_sampling.py:36-113).
+def project_and_pack_torch(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
+    """Everything ``sampling_4d`` does before the op (opus_sampling.py:36-113), as the
+    reference writes it: ~20 tensor ops over [B, T, N, Q, G*P, ...] temporaries.  Kept as the
+    statement of the semantics that ``project_and_pack`` (one HIP kernel) is tested against.
 
     sample_points [B, Q, T, G, P, 3] (metres), scale_weights [B, Q, G, T, P, L],
     occ2img [B, T*N, 4, 4].  Returns (loc [B*T*G, Q, P, 3], weights [B*G*T, Q, P, L]).
@@ -76,6 +81,64 @@ def project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, nu
     return loc, w
 
 
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _ProjectPack(torch.autograd.Function):
+    """opus_msmv_project_pack / _backward behind autograd (one kernel each way)."""
+
+    @staticmethod
+    def forward(ctx, sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps):
+        if not sample_points.is_cuda:
+            raise RuntimeError("project_and_pack runs on the GPU only; "
+                               "project_and_pack_torch is the tensor-op statement of it")
+        B, Q, T, G, P, three = sample_points.shape
+        assert three == 3
+        L = scale_weights.shape[-1]
+        N = int(num_views)
+        assert scale_weights.shape == (B, Q, G, T, P, L), "scale_weights must be [B,Q,G,T,P,L]"
+        assert occ2img.shape == (B, T * N, 4, 4), "occ2img must be [B,T*N,4,4]"
+        pts = sample_points.contiguous().float()
+        sw = scale_weights.contiguous().float()
+        mats = occ2img.contiguous().float()
+        loc = torch.empty((B * T * G, Q, P, 3), dtype=torch.float32, device=pts.device)
+        w = torch.empty((B * G * T, Q, P, L), dtype=torch.float32, device=pts.device)
+        lib = _lib.load()
+        with torch.cuda.device(pts.device):
+            _lib.check(lib.opus_msmv_project_pack(
+                _vp(pts), _vp(sw), _vp(mats), B, Q, T, G, P, L, N,
+                float(image_h), float(image_w), float(eps), _vp(loc), _vp(w),
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "opus_msmv_project_pack")
+        ctx.save_for_backward(pts, mats, loc)
+        ctx.dims = (B, Q, T, G, P, L, N, float(image_h), float(image_w), float(eps))
+        return loc, w
+
+    @staticmethod
+    def backward(ctx, dloc, dw):
+        pts, mats, loc = ctx.saved_tensors
+        B, Q, T, G, P, L, N, image_h, image_w, eps = ctx.dims
+        dloc = dloc.contiguous().float()
+        dw = dw.contiguous().float()
+        dpts = torch.empty_like(pts)
+        dsw = torch.empty((B, Q, G, T, P, L), dtype=torch.float32, device=pts.device)
+        lib = _lib.load()
+        with torch.cuda.device(pts.device):
+            _lib.check(lib.opus_msmv_project_pack_backward(
+                _vp(dloc), _vp(dw), _vp(pts), _vp(mats), _vp(loc), B, Q, T, G, P, L, N,
+                image_h, image_w, eps, _vp(dpts), _vp(dsw),
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                "opus_msmv_project_pack_backward")
+        return dpts, dsw, None, None, None, None, None
+
+
+def project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
+    """Same result as ``project_and_pack_torch`` from one HIP kernel (and one for the
+    backward): (loc [B*T*G, Q, P, 3], weights [B*G*T, Q, P, L]).  occ2img gets no gradient
+    (the reference builds it from image metadata, models/opus_transformer.py:105-110)."""
+    return _ProjectPack.apply(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
+
+
 def unpack(final, B, T, G):
     """[B*T*G, Q, C, P] -> [B, Q, G, T*P, C] (opus_sampling.py:119-122)."""
     _, Q, C, P = final.shape
@@ -83,10 +146,13 @@ def unpack(final, B, T, G):
     return final.flatten(3, 4)
 
 
-def sampling_4d(sample_points, mlvl_feats, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
+def sampling_4d(sample_points, mlvl_feats, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5,
+                fused=True):
     """Same contract as the reference's sampling_4d with channel-last features
-    [B*T*G, N, H, W, C]; returns [B, Q, G, T*P, C]."""
+    [B*T*G, N, H, W, C]; returns [B, Q, G, T*P, C].  ``fused=False`` runs the projection as
+    the reference's tensor ops instead of the HIP kernel (same result, for comparison)."""
     B, Q, T, G, P, _ = sample_points.shape
-    loc, w = project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
+    pack = project_and_pack if fused else project_and_pack_torch
+    loc, w = pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
     final = msmv_sampling(mlvl_feats, loc, w)
     return unpack(final, B, T, G)

@@ -3,7 +3,7 @@ import os
 
 import numpy as np
 
-from procedural import procedural_feats
+from procedural import procedural_feats, synthetic_occ2img  # noqa: F401
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -74,3 +74,15 @@ def random_case(seed, levels, B, N, C, Q, P, oob_frac=0.25, dtype=np.float32):
     w = (np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)).astype(dtype)
     grad_out = rng.standard_normal((B, Q, C, P)).astype(dtype)
     return feats, loc, w, grad_out
+
+
+def sampling4d_case(seed, B, Q, T, G, P, N=6, L=4, image_h=256, image_w=704):
+    """Random caller-side inputs in the reference's shapes: sample_points [B,Q,T,G,P,3] in the
+    occupancy range, softmax scale weights [B,Q,G,T,P,L], ring-of-cameras occ2img [B,T*N,4,4]."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform([-40, -40, -1.0], [40, 40, 5.4], (B, Q, T, G, P, 3)).astype(np.float32)
+    if Q > 1:
+        pts[0, 0] = 0.0                      # at the ego origin: visible in no camera
+    logits = rng.standard_normal((B, Q, G, T, P, L))
+    sw = (np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)).astype(np.float32)
+    return pts, sw, synthetic_occ2img(rng, B, T, N, image_h, image_w)

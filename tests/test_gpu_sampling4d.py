@@ -1,0 +1,156 @@
+"""GPU parity tests of the fused caller-side kernels (opus_msmv_project_pack and its backward,
+through the C ABI via opus_amd.opus_sampling) against the golden fixtures of the reference's
+sampling_4d and the caller-side CPU oracle.
+
+Bars: the chosen camera must be identical, except where some camera's visibility test sits
+within float rounding of its threshold (margin < 1e-4 of the image / 1e-4 m in depth: the
+projection is a 4-term float sum whose last bit depends on contraction); projected
+coordinates 1e-6 relative; packed weights bit-exact; gradients 1e-5 relative against the
+float64 analytic oracle and 1e-4 end to end (helpers.GRAD_RTOL)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import FWD_RTOL, GRAD_RTOL, assert_close, load_golden, sampling4d_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from opus_amd import opus_sampling
+    from opus_amd.csrc import wrapper
+    assert wrapper.MSMV_CUDA, "libopus_msmv.so must be loaded on the GPU box"
+    return opus_sampling
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def visibility_margin(pts, occ2img, image_h, image_w, N, eps=1e-5):
+    """Per point (in [B,T,G,Q,P] order): the smallest distance of any camera's (u, v, z)
+    from a visibility threshold, in float64."""
+    B, Q, T, G, P, _ = pts.shape
+    mats = occ2img.astype(np.float64).reshape(B, T, N, 4, 4)
+    p = np.concatenate([pts.astype(np.float64), np.ones(pts.shape[:-1] + (1,))], -1)
+    p = p.transpose(0, 2, 3, 1, 4, 5)                                  # [B,T,G,Q,P,4]
+    cam = np.einsum("btnij,btgqpj->btngqpi", mats[..., :3, :], p)
+    z = cam[..., 2]
+    hz = np.maximum(z, eps)
+    u, v = cam[..., 0] / hz / image_w, cam[..., 1] / hz / image_h
+    m = np.minimum.reduce([np.abs(u), np.abs(u - 1), np.abs(v), np.abs(v - 1), np.abs(z - eps)])
+    return m.min(axis=2)
+
+
+def check_packed(loc, w, ref_loc, ref_w, pts, occ2img, H, W, N, what):
+    same = loc[..., 2] == ref_loc[..., 2]
+    if not same.all():
+        B, Q, T, G, P, _ = pts.shape
+        margin = visibility_margin(pts, occ2img, H, W, N).reshape(B * T * G, Q, P)
+        assert (margin[~same] < 1e-4).all(), f"{what}: camera differs away from any threshold"
+        assert (~same).mean() < 1e-3, f"{what}: too many threshold cases to be rounding"
+    scale = np.abs(ref_loc[same]).max()
+    err = np.abs(loc[same].astype(np.float64) - ref_loc[same]).max()
+    assert err <= 1e-6 * scale, f"{what}: loc max|diff| {err:.3e} vs scale {scale:.3e}"
+    assert np.array_equal(w, ref_w), f"{what}: packed weights"
+    return same
+
+
+def test_project_pack_matches_golden(ops):
+    g = load_golden("g5_sampling4d")
+    H, W, N = int(g["image_h"]), int(g["image_w"]), int(g["num_views"])
+    loc, w = ops.project_and_pack(dev(g["sample_points"]), dev(g["scale_weights"]), dev(g["occ2img"]), H, W, N)
+    loc, w = loc.cpu().numpy(), w.cpu().numpy()
+    assert loc.shape == g["op_loc"].shape and w.shape == g["op_w"].shape
+    assert np.array_equal(loc[..., 2], g["op_loc"][..., 2])
+    assert_close(loc, g["op_loc"], 1e-6, "packed locations")
+    assert np.array_equal(w, g["op_w"])
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "tensor-ops"])
+def test_sampling_4d_end_to_end_matches_golden(ops, fused):
+    """Forward and every gradient of caller + op against the reference's own run."""
+    g, gg = load_golden("g5_sampling4d"), load_golden("g6_sampling4d_grad")
+    H, W, N = int(g["image_h"]), int(g["image_w"]), int(g["num_views"])
+    feats = [dev(g[f"feat_cf{i}"].transpose(0, 2, 3, 4, 1)).requires_grad_(True) for i in range(4)]
+    pts = dev(g["sample_points"]).requires_grad_(True)
+    sw = dev(g["scale_weights"]).requires_grad_(True)
+    out = ops.sampling_4d(pts, feats, sw, dev(g["occ2img"]), H, W, N, fused=fused)
+    assert_close(out.detach().cpu().numpy(), g["out"], FWD_RTOL, "sampling_4d")
+    out.backward(dev(gg["grad_out"]))
+    assert_close(pts.grad.cpu().numpy(), gg["d_sample_points"], GRAD_RTOL, "d sample_points")
+    assert_close(sw.grad.cpu().numpy(), gg["d_scale_weights"], GRAD_RTOL, "d scale_weights")
+    for i, f in enumerate(feats):
+        assert_close(f.grad.permute(0, 4, 1, 2, 3).cpu().numpy(), gg[f"d_feat_cf{i}"], GRAD_RTOL, f"d feat {i}")
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 8, 4, 2, 6, 4), (1, 37, 3, 5, 4, 6, 5), (1, 64, 2, 1, 1, 2, 4),
+                                   (3, 5, 1, 2, 7, 7, 4)],
+                         ids=["T8G4P2", "T3G5P4L5", "N2", "P7N7"])
+def test_project_pack_matches_oracle(ops, shape):
+    from oracle import sampling4d_oracle as so
+    B, Q, T, G, P, N, L = shape
+    H, W = 256, 704
+    pts, sw, occ2img = sampling4d_case(77 + Q, B, Q, T, G, P, N, L, H, W)
+    ref_loc, ref_w = so.project_pack(pts, sw, occ2img, H, W, N)
+    d_pts, d_sw = dev(pts).requires_grad_(True), dev(sw).requires_grad_(True)
+    loc, w = ops.project_and_pack(d_pts, d_sw, dev(occ2img), H, W, N)
+    same = check_packed(loc.detach().cpu().numpy(), w.detach().cpu().numpy(), ref_loc, ref_w,
+                        pts, occ2img, H, W, N, "fused vs oracle")
+
+    rng = np.random.default_rng(5)
+    dloc = rng.standard_normal(ref_loc.shape).astype(np.float32)
+    dloc[~same] = 0            # a different camera is a different function: compare the rest
+    dw = rng.standard_normal(ref_w.shape).astype(np.float32)
+    torch.autograd.backward([loc, w], [dev(dloc), dev(dw)])
+    ref_dpts, ref_dsw = so.project_pack_backward(dloc, dw, pts, occ2img, ref_loc, H, W, N)
+    assert_close(d_pts.grad.cpu().numpy(), ref_dpts, 1e-5, "d sample_points")
+    assert np.array_equal(d_sw.grad.cpu().numpy(), ref_dsw)
+
+
+def test_project_pack_full_size_matches_tensor_ops(ops):
+    """OPUS-L caller shape (B=1, Q=4800, T=8, G=4, P=2): the kernel against the reference's
+    own formulation run as tensor ops on the same device, forward and backward."""
+    B, Q, T, G, P, N, L = 1, 4800, 8, 4, 2, 6, 4
+    H, W = 256, 704
+    pts, sw, occ2img = sampling4d_case(9, B, Q, T, G, P, N, L, H, W)
+    a_pts, a_sw = dev(pts).requires_grad_(True), dev(sw).requires_grad_(True)
+    b_pts, b_sw = dev(pts).requires_grad_(True), dev(sw).requires_grad_(True)
+    loc, w = ops.project_and_pack(a_pts, a_sw, dev(occ2img), H, W, N)
+    rloc, rw = ops.project_and_pack_torch(b_pts, b_sw, dev(occ2img), H, W, N)
+    same = check_packed(loc.detach().cpu().numpy(), w.detach().cpu().numpy(),
+                        rloc.detach().cpu().numpy(), rw.detach().cpu().numpy(),
+                        pts, occ2img, H, W, N, "fused vs tensor ops")
+    views = np.rint(loc.detach().cpu().numpy()[..., 2] * (N - 1)).astype(int)
+    assert (np.bincount(views.ravel(), minlength=N) > 0).all(), "every camera should be chosen somewhere"
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    dloc = torch.randn(loc.shape, generator=gen, device="cuda") * dev(same.astype(np.float32))[..., None]
+    dw = torch.randn(w.shape, generator=gen, device="cuda")
+    torch.autograd.backward([loc, w], [dloc, dw])
+    torch.autograd.backward([rloc, rw], [dloc, dw])
+    assert_close(a_pts.grad.cpu().numpy(), b_pts.grad.cpu().numpy(), 1e-5, "d sample_points")
+    assert torch.equal(a_sw.grad, b_sw.grad)
+
+
+def test_project_pack_edge_cases(ops):
+    from opus_amd import _lib
+    H, W, N = 256, 704, 6
+    # empty query set
+    pts, sw, occ2img = sampling4d_case(1, 1, 0, 2, 2, 2, N)
+    loc, w = ops.project_and_pack(dev(pts), dev(sw), dev(occ2img), H, W, N)
+    assert loc.shape == (4, 0, 2, 3) and w.shape == (4, 0, 2, 4)
+    # N = 1 would divide by zero in the view coordinate; more than 32 points per query is
+    # beyond the op's limit
+    pts, sw, occ2img = sampling4d_case(1, 1, 4, 2, 2, 2, 1)
+    with pytest.raises(RuntimeError):
+        ops.project_and_pack(dev(pts), dev(sw), dev(occ2img), H, W, 1)
+    pts, sw, occ2img = sampling4d_case(1, 1, 4, 1, 1, 33, N)
+    with pytest.raises(RuntimeError):
+        ops.project_and_pack(dev(pts), dev(sw), dev(occ2img), H, W, N)
+    # CPU tensors are refused, not silently computed elsewhere
+    pts, sw, occ2img = sampling4d_case(1, 1, 4, 2, 2, 2, N)
+    with pytest.raises(RuntimeError):
+        ops.project_and_pack(torch.from_numpy(pts), torch.from_numpy(sw), torch.from_numpy(occ2img), H, W, N)
+    assert _lib.load().opus_msmv_version() >= 100

@@ -101,13 +101,13 @@ def test_msmv_sampling_pytorch_matches_golden():
 
 
 def test_sampling_4d_packing_matches_golden(oracle):
-    """project_and_pack / unpack reproduce what the reference's sampling_4d hands to and takes
+    """project_and_pack_torch / unpack reproduce what the reference's sampling_4d hands to and takes
     from the op (incl. first-valid-camera selection and the (B,T,G) / (B,G,T) packing)."""
     from opus_amd import opus_sampling
     g = load_golden("g5_sampling4d")
     pts = torch.from_numpy(g["sample_points"])
     B, Q, T, G, P, _ = pts.shape
-    loc, w = opus_sampling.project_and_pack(
+    loc, w = opus_sampling.project_and_pack_torch(
         pts, torch.from_numpy(g["scale_weights"]), torch.from_numpy(g["occ2img"]),
         int(g["image_h"]), int(g["image_w"]), int(g["num_views"]))
     assert loc.shape == g["op_loc"].shape and w.shape == g["op_w"].shape

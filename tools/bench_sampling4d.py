@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Caller-side fusion benchmark: the projection / camera selection / packing that sampling_4d
+does around the op (models/opus_sampling.py:36-113 of the reference), as ONE HIP kernel per
+direction (opus_msmv_project_pack[_backward]) against the same arithmetic as ~20 tensor ops on
+the same GPU, and the whole sampling_4d forward + backward either way.
+
+    python tools/bench_sampling4d.py [--variant L] [--iters 50]
+
+Prints one JSON line.  Algorithmic bytes of the fused kernels: 12 B of point + 4L B of weights
+read and the same written per sampled point (the T*N 4x4 matrices are 3 KB and stay in cache).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from opus_amd import opus_sampling  # noqa: E402
+from procedural import synthetic_occ2img  # noqa: E402
+
+LEVELS = [(64, 176), (32, 88), (16, 44), (8, 22)]
+VARIANTS = {"T": (600, 4), "S": (1200, 2), "M": (2400, 2), "L": (4800, 2)}
+T, G, N, C, H, W = 8, 4, 6, 64, 256, 704
+
+
+def timed(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3      # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="L", choices=list(VARIANTS))
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=1)
+    args = ap.parse_args()
+    Q, P = VARIANTS[args.variant]
+    B, L = args.batch, len(LEVELS)
+    dev = torch.device("cuda", 0)
+    import numpy as np
+    rng = np.random.default_rng(0)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    lo = torch.tensor([-40.0, -40.0, -1.0], device=dev)
+    hi = torch.tensor([40.0, 40.0, 5.4], device=dev)
+    pts = (torch.rand((B, Q, T, G, P, 3), generator=gen, device=dev) * (hi - lo) + lo).requires_grad_(True)
+    sw = torch.softmax(torch.randn((B, Q, G, T, P, L), generator=gen, device=dev), -1).requires_grad_(True)
+    occ2img = torch.from_numpy(synthetic_occ2img(rng, B, T, N, H, W)).to(dev)
+    feats = [torch.randn((B * T * G, N, h, w, C), generator=gen, device=dev).requires_grad_(True) for h, w in LEVELS]
+    npts = B * T * G * Q * P
+    dloc = torch.randn((B * T * G, Q, P, 3), generator=gen, device=dev)
+    dw = torch.randn((B * T * G, Q, P, L), generator=gen, device=dev)
+    gout = torch.randn((B, Q, G, T * P, C), generator=gen, device=dev)
+
+    res = {"variant": f"OPUS-{args.variant}", "points": npts, "iters": args.iters}
+    for name, fn in (("fused", opus_sampling.project_and_pack), ("tensor_ops", opus_sampling.project_and_pack_torch)):
+        with torch.no_grad():
+            res[f"pack_fwd_us_{name}"] = timed(lambda: fn(pts, sw, occ2img, H, W, N), args.iters)
+
+        def fwd_bwd():
+            pts.grad = sw.grad = None
+            loc, w = fn(pts, sw, occ2img, H, W, N)
+            torch.autograd.backward([loc, w], [dloc, dw])
+        res[f"pack_fwdbwd_us_{name}"] = timed(fwd_bwd, args.iters)
+
+        def chain(fused=(name == "fused")):
+            pts.grad = sw.grad = None
+            for f in feats:
+                f.grad = None
+            out = opus_sampling.sampling_4d(pts, feats, sw, occ2img, H, W, N, fused=fused)
+            out.backward(gout)
+        res[f"sampling_4d_fwdbwd_us_{name}"] = timed(chain, max(args.iters // 2, 5))
+    alg = npts * (12 + 4 * L) * 2
+    res["pack_alg_bytes"] = alg
+    res["pack_fwd_GBps_fused"] = alg / res["pack_fwd_us_fused"] / 1e3
+    res["speedup_pack_fwdbwd"] = res["pack_fwdbwd_us_tensor_ops"] / res["pack_fwdbwd_us_fused"]
+    res["speedup_sampling_4d_fwdbwd"] = res["sampling_4d_fwdbwd_us_tensor_ops"] / res["sampling_4d_fwdbwd_us_fused"]
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
