@@ -121,6 +121,27 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
                        void *workspace, size_t workspace_bytes, int flags, void *stream);
 
 /*
+ * Row-mode variants: the op fused with the permute its caller applies to the result
+ * (models/opus_sampling.py:119-122).  The op's batch is B' = Bs*T*G with slab
+ * b' = (bs*T + t)*G + g, as sampling_4d packs it (opus_sampling.py:104-107); out / grad_out are
+ * [Bs, Q, G, T*P, C] - what sampling_4d returns - instead of [B', Q, C, P], so the
+ * 78.6 MB (OPUS-L) permute-copy after the op, and its mirror image in the backward, disappear
+ * and every point's C channels are one contiguous row.  Everything else (feats, loc, weights,
+ * gradients, workspace size for B = Bs*T*G, flags, errors) is as in opus_msmv_forward_ex /
+ * opus_msmv_backward.
+ */
+int opus_msmv_forward_rows(int L, const float *const *feats, const int *hw,
+                           const float *loc, const float *weights,
+                           int Bs, int T, int G, int C, int N, int Q, int P,
+                           float *out, int flags, void *stream);
+
+int opus_msmv_backward_rows(int L, const float *grad_out, const float *const *feats, const int *hw,
+                            const float *loc, const float *weights,
+                            int Bs, int T, int G, int C, int N, int Q, int P,
+                            float *const *dfeats, float *dloc, float *dweights,
+                            void *workspace, size_t workspace_bytes, int flags, void *stream);
+
+/*
  * Caller-side fusion: everything sampling_4d does before it calls the op
  * (models/opus_sampling.py:36-113), in one launch.
  *   sample_points [B,Q,T,G,P,3] (metres), scale_weights [B,Q,G,T,P,L], occ2img [B,T*N,4,4]

@@ -41,6 +41,14 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "opus_msmv_forward_rows": (ctypes.c_int, [
+        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _i32p, ctypes.c_void_p, ctypes.c_void_p]
+        + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "opus_msmv_backward_rows": (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), _i32p,
+        ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
+        + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
+           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_project_pack": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
         + [ctypes.c_float] * 3 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -11,6 +11,37 @@ namespace {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+MsmvDiv make_div(int d)
+{
+    MsmvDiv r = {0, 0};
+    if (d >= 2) {
+        int l2 = 0;
+        while ((1ll << l2) < d)
+            ++l2;                                                // ceil(log2(d)), >= 1
+        const unsigned __int128 one = 1;
+        const unsigned __int128 num = one << (31 + l2);
+        r.magic = (uint32_t)((num + (unsigned)d - 1) / (unsigned)d);
+        r.shift = (uint32_t)(l2 - 1);
+    }
+    return r;
+}
+
+// Row mode (out / grad_out in [Bs, Q, G, T*P, C]): B must be Bs*T*G.
+int fill_rows(MsmvArgs &a, int T, int G)
+{
+    if (T < 1 || G < 1 || a.B % (T * G) != 0)
+        return OPUS_MSMV_EINVAL_DIMS;
+    a.rows = 1;
+    a.T = T;
+    a.G = G;
+    a.div_p = make_div(a.P);
+    a.div_q = make_div(a.Q);
+    a.div_t = make_div(T);
+    a.div_g = make_div(G);
+    a.div_tg = make_div(T * G);
+    return OPUS_MSMV_OK;
+}
+
 // Validates sizes and fills everything in MsmvArgs except the data pointers.
 int fill_common(MsmvArgs &a, int L, const int *hw, int B, int C, int N, int Q, int P)
 {
@@ -37,17 +68,9 @@ int fill_common(MsmvArgs &a, int L, const int *hw, int B, int C, int N, int Q, i
     a.L = L; a.B = B; a.C = C; a.N = N; a.Q = Q; a.P = P;
     a.npts = (int)npts;
     a.qp = Q * P;
-    a.qp_magic = 0;
-    a.qp_shift = 0;
-    if (a.qp >= 2) {
-        int l2 = 0;
-        while ((1ll << l2) < a.qp)
-            ++l2;                                            // ceil(log2(qp)), >= 1
-        const unsigned __int128 one = 1;
-        const unsigned __int128 num = one << (31 + l2);
-        a.qp_magic = (uint32_t)((num + (unsigned)a.qp - 1) / (unsigned)a.qp);
-        a.qp_shift = (uint32_t)(l2 - 1);
-    }
+    const MsmvDiv dqp = make_div(a.qp);
+    a.qp_magic = dqp.magic;
+    a.qp_shift = dqp.shift;
     return OPUS_MSMV_OK;
 }
 
@@ -83,13 +106,16 @@ const char *opus_msmv_strerror(int code)
     }
 }
 
-int opus_msmv_forward_ex(int L, const float *const *feats, const int *hw,
-                         const float *loc, const float *weights,
-                         int B, int C, int N, int Q, int P,
-                         float *out, int flags, void *stream)
+// T == 0: out is [B, Q, C, P]; otherwise row mode with B = Bs*T*G
+static int forward_impl(int L, const float *const *feats, const int *hw,
+                        const float *loc, const float *weights,
+                        int B, int T, int G, int C, int N, int Q, int P,
+                        float *out, int flags, void *stream)
 {
     MsmvArgs a = {};
-    const int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    if (rc == OPUS_MSMV_OK && T)
+        rc = fill_rows(a, T, G);
     if (rc != OPUS_MSMV_OK)
         return rc;
     if (flags & ~OPUS_MSMV_FWD_GENERIC)
@@ -112,12 +138,30 @@ int opus_msmv_forward_ex(int L, const float *const *feats, const int *hw,
     return msmv_launch_forward(a, (hipStream_t)stream, generic) == hipSuccess ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
 }
 
+int opus_msmv_forward_ex(int L, const float *const *feats, const int *hw,
+                         const float *loc, const float *weights,
+                         int B, int C, int N, int Q, int P,
+                         float *out, int flags, void *stream)
+{
+    return forward_impl(L, feats, hw, loc, weights, B, 0, 0, C, N, Q, P, out, flags, stream);
+}
+
 int opus_msmv_forward(int L, const float *const *feats, const int *hw,
                       const float *loc, const float *weights,
                       int B, int C, int N, int Q, int P,
                       float *out, void *stream)
 {
-    return opus_msmv_forward_ex(L, feats, hw, loc, weights, B, C, N, Q, P, out, 0, stream);
+    return forward_impl(L, feats, hw, loc, weights, B, 0, 0, C, N, Q, P, out, 0, stream);
+}
+
+int opus_msmv_forward_rows(int L, const float *const *feats, const int *hw,
+                           const float *loc, const float *weights,
+                           int Bs, int T, int G, int C, int N, int Q, int P,
+                           float *out, int flags, void *stream)
+{
+    if (Bs < 0 || T < 1 || G < 1 || (long long)Bs * T * G > INT_MAX)
+        return OPUS_MSMV_EINVAL_DIMS;
+    return forward_impl(L, feats, hw, loc, weights, Bs * T * G, T, G, C, N, Q, P, out, flags, stream);
 }
 
 size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int P, int flags)
@@ -134,14 +178,16 @@ size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int
     return msmv_backward_owner_workspace(B, N, Q, P);
 }
 
-int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, const int *hw,
-                       const float *loc, const float *weights,
-                       int B, int C, int N, int Q, int P,
-                       float *const *dfeats, float *dloc, float *dweights,
-                       void *workspace, size_t workspace_bytes, int flags, void *stream)
+static int backward_impl(int L, const float *grad_out, const float *const *feats, const int *hw,
+                         const float *loc, const float *weights,
+                         int B, int T, int G, int C, int N, int Q, int P,
+                         float *const *dfeats, float *dloc, float *dweights,
+                         void *workspace, size_t workspace_bytes, int flags, void *stream)
 {
     MsmvArgs a = {};
-    const int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    if (rc == OPUS_MSMV_OK && T)
+        rc = fill_rows(a, T, G);
     if (rc != OPUS_MSMV_OK)
         return rc;
     const int algo = flags & 0xF;
@@ -192,6 +238,28 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
         e = msmv_launch_backward_atomic(a, (hipStream_t)stream, accumulate);
     }
     return e == hipSuccess ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
+}
+
+int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, const int *hw,
+                       const float *loc, const float *weights,
+                       int B, int C, int N, int Q, int P,
+                       float *const *dfeats, float *dloc, float *dweights,
+                       void *workspace, size_t workspace_bytes, int flags, void *stream)
+{
+    return backward_impl(L, grad_out, feats, hw, loc, weights, B, 0, 0, C, N, Q, P, dfeats, dloc, dweights,
+                         workspace, workspace_bytes, flags, stream);
+}
+
+int opus_msmv_backward_rows(int L, const float *grad_out, const float *const *feats, const int *hw,
+                            const float *loc, const float *weights,
+                            int Bs, int T, int G, int C, int N, int Q, int P,
+                            float *const *dfeats, float *dloc, float *dweights,
+                            void *workspace, size_t workspace_bytes, int flags, void *stream)
+{
+    if (Bs < 0 || T < 1 || G < 1 || (long long)Bs * T * G > INT_MAX)
+        return OPUS_MSMV_EINVAL_DIMS;
+    return backward_impl(L, grad_out, feats, hw, loc, weights, Bs * T * G, T, G, C, N, Q, P, dfeats, dloc, dweights,
+                         workspace, workspace_bytes, flags, stream);
 }
 
 static int check_project_dims(int B, int Q, int T, int G, int P, int L, int N)

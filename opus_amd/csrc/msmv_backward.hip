@@ -50,6 +50,7 @@ msmv_bwd_atomic(const MsmvArgs a)
         const int b = msmv_batch_of(pt, a);
         const int bq = pt / a.P, p = pt - bq * a.P;
         const size_t slab = (size_t)b * a.N + (view_ok ? view : 0);
+        const float *grow = a.rows ? a.gout + (size_t)msmv_row_of(pt, a) * a.C : nullptr;
         float gx = 0.f, gy = 0.f;
         for (int l = 0; l < a.L; ++l) {
             const int H = a.lvl[l].H, W = a.lvl[l].W;
@@ -61,7 +62,7 @@ msmv_bwd_atomic(const MsmvArgs a)
                 const float *base = a.lvl[l].feat + off;
                 float *gbase = a.lvl[l].dfeat + off;
                 for (int c = lane; c < a.C; c += 64) {
-                    const float top = a.gout[((size_t)bq * a.C + c) * a.P + p];
+                    const float top = grow ? grow[c] : a.gout[((size_t)bq * a.C + c) * a.P + p];
                     const float tgv = top * wl;
                     float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
                     if (t.c1) { v1 = base[(size_t)t.o1 * a.C + c]; unsafeAtomicAdd(gbase + (size_t)t.o1 * a.C + c, t.w1 * tgv); }
@@ -94,7 +95,7 @@ msmv_bwd_atomic(const MsmvArgs a)
 // owner algorithm: binning
 // ======================================================================================
 struct BinEntry {       // 32 bytes: everything the d-feat pass needs about a point
-    int pt;
+    int pt;             // point index; in row mode the point's grad_out row instead
     float x, y;
     float w[5];         // the point's scale weights (L <= 5; unused slots are 0)
 };
@@ -253,7 +254,8 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
         if (a.L <= 4)
             wv[4] = __int_as_float(key / BIN_PER_VIEW);     // the view, for the gather pass
         float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + hist[key] + rank);
-        e[0] = make_float4(__int_as_float((int)pt), x, y, wv[0]);
+        const int id = a.rows ? msmv_row_of((int)pt, a) : (int)pt;
+        e[0] = make_float4(__int_as_float(id), x, y, wv[0]);
         e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
     }
 }
@@ -614,6 +616,8 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
         int pt = act ? pt_raw : a.npts - 1;
         float lx, ly, wl[NL];
         int view, b;
+        [[maybe_unused]] int grow = 0;           // row mode: the point's grad_out row
+        static_assert(PT != MSMV_PT_ROWS || SORTED, "row mode walks the bin entries");
         if constexpr (SORTED) {
             // slot pt of the entry array: slab b holds offsets[b][keys] entries from b*QP on
             b = msmv_batch_of(pt, a);
@@ -624,6 +628,10 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
             if (n_b == 0)
                 act = false;                 // (the entry read above is then stale but in bounds)
             pt = act ? __float_as_int(e0.x) : a.npts - 1;
+            if constexpr (PT == MSMV_PT_ROWS) {
+                grow = pt;
+                pt = msmv_pt_of_row(grow, a);
+            }
             lx = e0.y;
             ly = e0.z;
             const float wv[5] = {e0.w, e1.x, e1.y, e1.z, e1.w};
@@ -664,7 +672,9 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
 
         // this row's 4 channels of grad_out for its point (inverse of the forward's store)
         float4 gq;
-        if constexpr (PT == 1) {
+        if constexpr (PT == MSMV_PT_ROWS) {
+            gq = ld4(a.gout + (size_t)grow * 64 + l16 * 4);
+        } else if constexpr (PT == 1) {
             gq = ld4(a.gout + (size_t)pt * 64 + l16 * 4);
         } else if constexpr (SORTED && PT == 2) {
             // rows no longer hold the p = 0,1 pair of one query: fetch the row's 4 channels x 2 p
@@ -749,7 +759,9 @@ hipError_t launch_gather(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
     const int ngroups = (a.npts + 3) / 4;
     const int per_block = (GAT_THREADS / 64) * GAT_GROUPS_PER_WAVE;
     const int nblk = (ngroups + per_block - 1) / per_block;
-    switch (a.P) {
+    switch (a.rows ? MSMV_PT_ROWS : a.P) {
+    // row mode: a point's gradient is one contiguous row whatever P is, so bin order always pays
+    case MSMV_PT_ROWS: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, MSMV_PT_ROWS, true>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     case 1: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 1, true>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     case 2: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 2, true>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     // P = 4 / other P: bin order would fetch 4x (Px) the gradient bytes per row; input order wins
@@ -836,7 +848,8 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     geo.tiles_per_b = per_view * a.N;
     const long long ntiles = (long long)geo.tiles_per_b * a.B;
     const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
-    switch ((stages & 2) ? a.P : -1) {
+    // in row mode the entries carry grad_out rows, which is exactly the P = 1 addressing
+    switch ((stages & 2) ? (a.rows ? 1 : a.P) : -1) {
     case -1: break;
     case 1: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<1>, grid, block, 0, s, a, ws, geo); break;
     case 2: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<2>, grid, block, 0, s, a, ws, geo); break;

@@ -5,11 +5,19 @@
 
 #define MSMV_MAX_LEVELS 8
 #define MSMV_WAVE 64
+#define MSMV_PT_ROWS (-1)     // template value of "points per query" that selects row mode
 
 struct MsmvLevel {
     const float *feat;   // [B, N, H, W, C]
     float *dfeat;        // same shape (backward only)
     int H, W;
+};
+
+// Unsigned division by a run-time constant d without a divide: for d >= 2 the host sets
+// l = ceil(log2 d), magic = ceil(2^(31+l) / d) (< 2^32) and shift = l - 1; then
+// x / d == umulhi(x, magic) >> shift for every x < 2^31.  d == 1 is encoded as magic == 0.
+struct MsmvDiv {
+    uint32_t magic, shift;
 };
 
 // Passed by value as the kernel argument block.
@@ -26,7 +34,18 @@ struct MsmvArgs {
     int qp;                // Q*P
     uint32_t qp_magic;     // floor-division of a point index by Q*P without a divide:
     uint32_t qp_shift;     //   pt / qp == umulhi(pt, qp_magic) >> qp_shift   (pt < 2^31)
+    // Row mode (rows != 0): B = Bs*T*G with batch slab b = (bs*T + t)*G + g, and out / gout are
+    // [Bs, Q, G, T*P, C]: the C channels of point (b, q, p) are contiguous at row
+    // (((bs*Q + q)*G + g)*T + t)*P + p - the layout the caller of the reference's op permutes
+    // its result into (models/opus_sampling.py:119-122).
+    int rows, T, G;
+    MsmvDiv div_p, div_q, div_t, div_g, div_tg;
 };
+
+__device__ __forceinline__ uint32_t msmv_div(uint32_t x, MsmvDiv d)
+{
+    return d.magic ? __umulhi(x, d.magic) >> d.shift : x;
+}
 
 // pt / (Q*P) for 0 <= pt < 2^31.  For d = Q*P >= 2 the host sets l = ceil(log2 d),
 // qp_magic = ceil(2^(31+l) / d) (< 2^32) and qp_shift = l - 1, which is exact for every
@@ -34,6 +53,30 @@ struct MsmvArgs {
 __device__ __forceinline__ int msmv_batch_of(int pt, const MsmvArgs &a)
 {
     return a.qp == 1 ? pt : (int)(__umulhi((uint32_t)pt, a.qp_magic) >> a.qp_shift);
+}
+
+// Row mode: output row of point pt, and its inverse.
+__device__ __forceinline__ int msmv_row_of(int pt, const MsmvArgs &a)
+{
+    const uint32_t b = (uint32_t)msmv_batch_of(pt, a);
+    const uint32_t rem = (uint32_t)pt - b * (uint32_t)a.qp;           // q*P + p
+    const uint32_t q = msmv_div(rem, a.div_p), p = rem - q * a.P;
+    const uint32_t bs = msmv_div(b, a.div_tg), r = b - bs * (uint32_t)(a.T * a.G);
+    const uint32_t t = msmv_div(r, a.div_g), g = r - t * a.G;
+    return (int)((((bs * a.Q + q) * a.G + g) * a.T + t) * a.P + p);
+}
+
+__device__ __forceinline__ int msmv_pt_of_row(int row, const MsmvArgs &a)
+{
+    uint32_t x = (uint32_t)row;
+    uint32_t y = msmv_div(x, a.div_p);
+    const uint32_t p = x - y * a.P;
+    x = msmv_div(y, a.div_t);
+    const uint32_t t = y - x * a.T;
+    y = msmv_div(x, a.div_g);
+    const uint32_t g = x - y * a.G;
+    const uint32_t bs = msmv_div(y, a.div_q), q = y - bs * a.Q;
+    return (int)((((bs * a.T + t) * a.G + g) * a.Q + q) * a.P + p);
 }
 
 // One bilinear tap of one level: geometry shared by all channels of a point.

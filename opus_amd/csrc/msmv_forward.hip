@@ -10,7 +10,9 @@
 // are computed redundantly by the 16 lanes of a row (cheaper than a broadcast).  The
 // [B,Q,C,P] output is P-strided per channel; for P in {1,2,4} the 4 points of a wave are
 // whole queries and the rows exchange values (2x2 / 4x4 lane transposes) so that every
-// lane still issues one 16-byte store into a contiguous 1-KiB run per wave.
+// lane still issues one 16-byte store into a contiguous 1-KiB run per wave.  In row mode
+// (PT == MSMV_PT_ROWS: output [Bs,Q,G,T*P,C]) a point's 64 channels are one contiguous
+// 256-byte row and no exchange is needed.
 #include "msmv_common.h"
 #include "msmv_launch.h"
 
@@ -61,6 +63,9 @@ msmv_fwd_c64(const MsmvArgs a)
         const bool view_ok = view >= 0;
         const int b = msmv_batch_of(pt, a);
         const size_t slab = (size_t)b * a.N + (view_ok ? view : 0);
+        [[maybe_unused]] int orow = 0;
+        if constexpr (PT == MSMV_PT_ROWS)
+            orow = msmv_row_of(pt, a);
 
         MsmvTap tap[NL];
         float4 v[NL][4];
@@ -94,7 +99,10 @@ msmv_fwd_c64(const MsmvArgs a)
             acc.w = t.ok ? acc.w + val.w * wl[l] : acc.w;
         }
 
-        if constexpr (PT == 1) {
+        if constexpr (PT == MSMV_PT_ROWS) {
+            if (act)
+                *reinterpret_cast<float4 *>(a.out + (size_t)orow * 64 + l16 * 4) = acc;
+        } else if constexpr (PT == 1) {
             if (act)
                 *reinterpret_cast<float4 *>(a.out + (size_t)pt * 64 + l16 * 4) = acc;
         } else if constexpr (PT == 2) {
@@ -149,6 +157,7 @@ msmv_fwd_generic(const MsmvArgs a)
         const int b = msmv_batch_of(pt, a);
         const int bq = pt / a.P, p = pt - bq * a.P;
         const size_t slab = (size_t)b * a.N + (view_ok ? view : 0);
+        const size_t row = a.rows ? (size_t)msmv_row_of(pt, a) : 0;
         for (int c = lane; c < a.C; c += 64) {
             float acc = 0.f;
             for (int l = 0; l < a.L; ++l) {
@@ -164,7 +173,10 @@ msmv_fwd_generic(const MsmvArgs a)
                 const float val = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;
                 acc += val * a.w[(size_t)pt * a.L + l];
             }
-            a.out[((size_t)bq * a.C + c) * a.P + p] = acc;
+            if (a.rows)
+                a.out[row * a.C + c] = acc;
+            else
+                a.out[((size_t)bq * a.C + c) * a.P + p] = acc;
         }
     }
 }
@@ -175,7 +187,8 @@ hipError_t launch_c64(const MsmvArgs &a, hipStream_t s)
     const int ngroups = (a.npts + 3) / 4;
     const int per_block = (FWD_THREADS / 64) * FWD_GROUPS_PER_WAVE;
     const int nblk = (ngroups + per_block - 1) / per_block;
-    switch (a.P) {
+    switch (a.rows ? MSMV_PT_ROWS : a.P) {
+    case MSMV_PT_ROWS: hipLaunchKernelGGL((msmv_fwd_c64<NL, MSMV_PT_ROWS>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
     case 1: hipLaunchKernelGGL((msmv_fwd_c64<NL, 1>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
     case 2: hipLaunchKernelGGL((msmv_fwd_c64<NL, 2>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
     case 4: hipLaunchKernelGGL((msmv_fwd_c64<NL, 4>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;

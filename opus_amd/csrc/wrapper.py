@@ -119,16 +119,31 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def msmv_forward(feats, loc, w, flags=0):
-    """Raw forward: feats channel-last [B,N,H,W,C] -> out [B,Q,C,P] (no autograd)."""
+def _check_rows(B, rows):
+    """rows = (T, G): the op's batch is Bs*T*G and out / grad_out are [Bs, Q, G, T*P, C]."""
+    T, G = int(rows[0]), int(rows[1])
+    if T < 1 or G < 1 or B % (T * G) != 0:
+        raise RuntimeError(f"row mode: batch {B} is not a multiple of T*G = {T}*{G}")
+    return B // (T * G), T, G
+
+
+def msmv_forward(feats, loc, w, flags=0, rows=None):
+    """Raw forward: feats channel-last [B,N,H,W,C] -> out [B,Q,C,P] (no autograd).
+    With ``rows=(T, G)``: B = Bs*T*G and out is [Bs, Q, G, T*P, C], i.e. already in the layout
+    the reference's sampling_4d returns (models/opus_sampling.py:119-122)."""
     L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
-    out = torch.empty((B, Q, C, P), dtype=torch.float32, device=loc.device)
     lib = _lib.load()
+    fptrs, hw_arr = _lib.ptr_array([f.data_ptr() for f in feats]), _lib.int_array(hw)
     with torch.cuda.device(loc.device):
-        rc = lib.opus_msmv_forward_ex(
-            L, _lib.ptr_array([f.data_ptr() for f in feats]), _lib.int_array(hw),
-            loc.data_ptr(), w.data_ptr(), B, C, N, Q, P, out.data_ptr(), flags,
-            _stream_ptr(loc.device))
+        if rows is None:
+            out = torch.empty((B, Q, C, P), dtype=torch.float32, device=loc.device)
+            rc = lib.opus_msmv_forward_ex(L, fptrs, hw_arr, loc.data_ptr(), w.data_ptr(), B, C, N, Q, P,
+                                          out.data_ptr(), flags, _stream_ptr(loc.device))
+        else:
+            Bs, T, G = _check_rows(B, rows)
+            out = torch.empty((Bs, Q, G, T * P, C), dtype=torch.float32, device=loc.device)
+            rc = lib.opus_msmv_forward_rows(L, fptrs, hw_arr, loc.data_ptr(), w.data_ptr(), Bs, T, G, C, N, Q, P,
+                                            out.data_ptr(), flags, _stream_ptr(loc.device))
     _lib.check(rc, "opus_msmv_forward")
     return out
 
@@ -139,13 +154,19 @@ def backward_workspace_bytes(feats, loc, w, flags=0):
     return _lib.load().opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags)
 
 
-def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None, flags=0):
+def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None, flags=0, rows=None):
     """Raw backward into caller-owned buffers (no allocation here when ``workspace`` is
-    given).  ``flags``: algorithm | ACCUMULATE | STAGE_* bits of include/opus_msmv.h."""
+    given).  ``flags``: algorithm | ACCUMULATE | STAGE_* bits of include/opus_msmv.h.
+    ``rows=(T, G)``: grad_out is [Bs, Q, G, T*P, C] (see msmv_forward)."""
     L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
-    if not grad_out.is_contiguous() or tuple(grad_out.shape) != (B, Q, C, P) \
+    if rows is None:
+        want = (B, Q, C, P)
+    else:
+        Bs, T, G = _check_rows(B, rows)
+        want = (Bs, Q, G, T * P, C)
+    if not grad_out.is_contiguous() or tuple(grad_out.shape) != want \
             or grad_out.dtype != torch.float32 or grad_out.device != loc.device:
-        raise RuntimeError("grad_output must be a contiguous float32 [B,Q,C,P] tensor on the inputs' device")
+        raise RuntimeError(f"grad_output must be a contiguous float32 {list(want)} tensor on the inputs' device")
     for d, f in zip(dfeats, feats):
         if d.shape != f.shape or not d.is_contiguous() or d.dtype != torch.float32 or d.device != f.device:
             raise RuntimeError("d feats must match feats in shape, dtype and device and be contiguous")
@@ -156,16 +177,19 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
         need = lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags)
         if workspace is None:
             workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=loc.device)
-        rc = lib.opus_msmv_backward(
-            L, grad_out.data_ptr(), _lib.ptr_array([f.data_ptr() for f in feats]),
-            _lib.int_array(hw), loc.data_ptr(), w.data_ptr(), B, C, N, Q, P,
-            _lib.ptr_array([d.data_ptr() for d in dfeats]), dloc.data_ptr(), dw.data_ptr(),
-            workspace.data_ptr(), workspace.numel() * workspace.element_size(), flags,
-            _stream_ptr(loc.device))
+        head = (L, grad_out.data_ptr(), _lib.ptr_array([f.data_ptr() for f in feats]),
+                _lib.int_array(hw), loc.data_ptr(), w.data_ptr())
+        tail = (_lib.ptr_array([d.data_ptr() for d in dfeats]), dloc.data_ptr(), dw.data_ptr(),
+                workspace.data_ptr(), workspace.numel() * workspace.element_size(), flags,
+                _stream_ptr(loc.device))
+        if rows is None:
+            rc = lib.opus_msmv_backward(*head, B, C, N, Q, P, *tail)
+        else:
+            rc = lib.opus_msmv_backward_rows(*head, Bs, T, G, C, N, Q, P, *tail)
     _lib.check(rc, "opus_msmv_backward")
 
 
-def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None):
+def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None):
     """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them."""
     flags = _BWD_ALGOS[_bwd_algo if algo is None else algo]
     if dfeats is None:
@@ -174,7 +198,7 @@ def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None):
         flags = _lib.BWD_ATOMIC | _lib.BWD_ACCUMULATE
     dloc = torch.empty_like(loc)
     dw = torch.empty_like(w)
-    msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, flags=flags)
+    msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, flags=flags, rows=rows)
     return dfeats, dloc, dw
 
 
@@ -207,6 +231,31 @@ class MSMVSamplingC23456(_MSMVSampling):
     def forward(ctx, feat_c2, feat_c3, feat_c4, feat_c5, feat_c6, sampling_locations, scale_weights):
         return _MSMVSampling.forward(ctx, feat_c2, feat_c3, feat_c4, feat_c5, feat_c6,
                                      sampling_locations, scale_weights)
+
+
+class MSMVSamplingRows(torch.autograd.Function):
+    """The op fused with its caller's un-pack (no counterpart in the reference's wrapper: it is
+    sampling_4d's msmv_sampling call + the permute of models/opus_sampling.py:116-122 as one
+    launch each way).  apply(T, G, *feats, loc, weights) -> [Bs, Q, G, T*P, C]."""
+
+    @staticmethod
+    def forward(ctx, T, G, *args):
+        *feats, sampling_locations, scale_weights = args
+        ctx.save_for_backward(*feats, sampling_locations, scale_weights)
+        ctx.rows = (T, G)
+        return msmv_forward(feats, sampling_locations, scale_weights, rows=ctx.rows)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        *feats, sampling_locations, scale_weights = ctx.saved_tensors
+        dfeats, dloc, dw = msmv_backward(grad_output.contiguous(), feats,
+                                         sampling_locations, scale_weights, rows=ctx.rows)
+        return (None, None, *dfeats, dloc, dw)
+
+
+def msmv_sampling_rows(mlvl_feats, sampling_locations, scale_weights, num_frames, num_groups):
+    """msmv_sampling + sampling_4d's un-pack: [Bs*T*G, ...] inputs -> [Bs, Q, G, T*P, C]."""
+    return MSMVSamplingRows.apply(num_frames, num_groups, *mlvl_feats, sampling_locations, scale_weights)
 
 
 def msmv_sampling(mlvl_feats, sampling_locations, scale_weights):

@@ -22,7 +22,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .csrc.wrapper import msmv_sampling
+from .csrc.wrapper import msmv_sampling, msmv_sampling_rows
 
 
 def relayout_features(mlvl_feats, num_frames, num_views, num_groups):
@@ -149,10 +149,15 @@ def unpack(final, B, T, G):
 def sampling_4d(sample_points, mlvl_feats, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5,
                 fused=True):
     """Same contract as the reference's sampling_4d with channel-last features
-    [B*T*G, N, H, W, C]; returns [B, Q, G, T*P, C].  ``fused=False`` runs the projection as
-    the reference's tensor ops instead of the HIP kernel (same result, for comparison)."""
+    [B*T*G, N, H, W, C]; returns [B, Q, G, T*P, C].  ``fused=False`` runs the projection and
+    the un-pack as the reference's tensor ops around the plain op (same result, for
+    comparison)."""
     B, Q, T, G, P, _ = sample_points.shape
-    pack = project_and_pack if fused else project_and_pack_torch
-    loc, w = pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
+    if fused:
+        # two launches forward (project + pack, then the op writing [B,Q,G,T*P,C] directly);
+        # no [B,T,N,Q,G*P,...] temporaries and no permute copy in either direction
+        loc, w = project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
+        return msmv_sampling_rows(mlvl_feats, loc, w, T, G)
+    loc, w = project_and_pack_torch(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
     final = msmv_sampling(mlvl_feats, loc, w)
     return unpack(final, B, T, G)

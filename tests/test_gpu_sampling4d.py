@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FWD_RTOL, GRAD_RTOL, assert_close, load_golden, sampling4d_case
+from helpers import (FWD_RTOL, GRAD_RTOL, REAL_LEVELS, TINY_LEVELS, assert_close, load_golden,
+                     random_case, sampling4d_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -154,3 +155,77 @@ def test_project_pack_edge_cases(ops):
     with pytest.raises(RuntimeError):
         ops.project_and_pack(torch.from_numpy(pts), torch.from_numpy(sw), torch.from_numpy(occ2img), H, W, N)
     assert _lib.load().opus_msmv_version() >= 100
+
+
+# ---------------------------------------------------------------- row mode (op + un-pack)
+ROW_CASES = [
+    # Bs, T, G, Q, P, C, levels
+    (1, 8, 4, 50, 2, 64, REAL_LEVELS),
+    (2, 3, 2, 33, 4, 64, REAL_LEVELS),
+    (1, 2, 5, 17, 1, 64, REAL_LEVELS),
+    (1, 3, 1, 9, 7, 64, REAL_LEVELS),
+    (2, 1, 3, 21, 2, 64, REAL_LEVELS + [(4, 11)]),
+    (2, 2, 3, 11, 3, 8, TINY_LEVELS),
+    (1, 1, 1, 1, 1, 64, REAL_LEVELS),
+]
+
+
+@pytest.mark.parametrize("case", ROW_CASES, ids=lambda c: "Bs%dT%dG%dQ%dP%dC%dL%d" % (*c[:6], len(c[6])))
+def test_row_mode_equals_op_plus_unpack(ops, case):
+    """opus_msmv_forward_rows / _backward_rows against the plain entry points with the
+    reference's permute applied around them: same arithmetic, another store / load address."""
+    from opus_amd.csrc import wrapper as wr
+    Bs, T, G, Q, P, C, levels = case
+    B = Bs * T * G
+    feats, loc, w, _ = random_case(4242 + Q, levels, B, 6, C, Q, P)
+    f = [dev(x) for x in feats]
+    l, ww = dev(loc), dev(w)
+    plain = wr.msmv_forward(f, l, ww)
+    rows = wr.msmv_forward(f, l, ww, rows=(T, G))
+    assert rows.shape == (Bs, Q, G, T * P, C)
+    assert torch.equal(rows, ops.unpack(plain, Bs, T, G).contiguous()), "forward must be bit-identical"
+
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    g_rows = torch.randn(rows.shape, generator=gen, device="cuda")
+    # the same gradient in the op's own layout: adjoint of unpack
+    g_plain = g_rows.reshape(Bs, Q, G, T, P, C).permute(0, 3, 2, 1, 5, 4).reshape(B, Q, C, P).contiguous()
+    algos = ["atomic", "owner"] if C == 64 and len(levels) in (4, 5) else ["atomic"]
+    for algo in algos:
+        df_p, dl_p, dw_p = wr.msmv_backward(g_plain, f, l, ww, algo=algo)
+        df_r, dl_r, dw_r = wr.msmv_backward(g_rows, f, l, ww, algo=algo, rows=(T, G))
+        for i, (a, b) in enumerate(zip(df_r, df_p)):
+            assert_close(a.cpu().numpy(), b.cpu().numpy(), GRAD_RTOL, f"{algo} dfeat{i}")
+        assert_close(dl_r.cpu().numpy(), dl_p.cpu().numpy(), 1e-5, f"{algo} dloc")
+        assert_close(dw_r.cpu().numpy(), dw_p.cpu().numpy(), 1e-5, f"{algo} dw")
+        assert (dl_r[..., 2] == 0).all()
+
+
+def test_row_mode_rejects_bad_batch(ops):
+    from opus_amd.csrc import wrapper as wr
+    feats, loc, w, _ = random_case(1, TINY_LEVELS, 6, 6, 8, 4, 2)
+    with pytest.raises(RuntimeError):
+        wr.msmv_forward([dev(x) for x in feats], dev(loc), dev(w), rows=(4, 1))     # 6 % 4 != 0
+
+
+def test_row_mode_full_size(ops):
+    """OPUS-L and OPUS-T sizes: forward bit-identical to op + permute; backward agrees."""
+    from opus_amd.csrc import wrapper as wr
+    for Q, P in ((4800, 2), (600, 4)):
+        gen = torch.Generator(device="cuda").manual_seed(Q)
+        T, G, B, N, C = 8, 4, 32, 6, 64
+        f = [torch.randn((B, N, h, w_, C), generator=gen, device="cuda") for h, w_ in REAL_LEVELS]
+        xy = torch.rand((B, Q, P, 2), generator=gen, device="cuda") * 1.2 - 0.1
+        view = torch.randint(0, N, (B, Q, P, 1), generator=gen, device="cuda").float() / (N - 1)
+        l = torch.cat([xy, view], -1).contiguous()
+        ww = torch.softmax(torch.randn((B, Q, P, 4), generator=gen, device="cuda"), -1)
+        plain = wr.msmv_forward(f, l, ww)
+        rows = wr.msmv_forward(f, l, ww, rows=(T, G))
+        assert torch.equal(rows, ops.unpack(plain, 1, T, G).contiguous())
+        g_rows = torch.randn(rows.shape, generator=gen, device="cuda")
+        g_plain = g_rows.reshape(1, Q, G, T, P, C).permute(0, 3, 2, 1, 5, 4).reshape(B, Q, C, P).contiguous()
+        df_p, dl_p, dw_p = wr.msmv_backward(g_plain, f, l, ww, algo="owner")
+        df_r, dl_r, dw_r = wr.msmv_backward(g_rows, f, l, ww, algo="owner", rows=(T, G))
+        for i, (a, b) in enumerate(zip(df_r, df_p)):
+            assert_close(a.cpu().numpy(), b.cpu().numpy(), GRAD_RTOL, f"P{P} dfeat{i}")
+        assert_close(dl_r.cpu().numpy(), dl_p.cpu().numpy(), 1e-5, f"P{P} dloc")
+        assert_close(dw_r.cpu().numpy(), dw_p.cpu().numpy(), 1e-5, f"P{P} dw")

@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-from opus_amd import opus_sampling  # noqa: E402
+from opus_amd import _lib, opus_sampling  # noqa: E402
+from opus_amd.csrc import wrapper  # noqa: E402
 from procedural import synthetic_occ2img  # noqa: E402
 
 LEVELS = [(64, 176), (32, 88), (16, 44), (8, 22)]
@@ -83,6 +84,30 @@ def main():
             out = opus_sampling.sampling_4d(pts, feats, sw, occ2img, H, W, N, fused=fused)
             out.backward(gout)
         res[f"sampling_4d_fwdbwd_us_{name}"] = timed(chain, max(args.iters // 2, 5))
+    # the op alone, in its own output layout + the caller's permute copy, against row mode
+    with torch.no_grad():
+        loc, w = opus_sampling.project_and_pack(pts, sw, occ2img, H, W, N)
+        fd = [f.detach() for f in feats]
+        plain = wrapper.msmv_forward(fd, loc, w)
+        res["op_fwd_us_plain"] = timed(lambda: wrapper.msmv_forward(fd, loc, w), args.iters)
+        res["unpack_copy_us"] = timed(lambda: opus_sampling.unpack(plain, B, T, G).contiguous(), args.iters)
+        res["op_fwd_us_rows"] = timed(lambda: wrapper.msmv_forward(fd, loc, w, rows=(T, G)), args.iters)
+        g_plain = torch.randn_like(plain)
+        res["op_bwd_us_plain"] = timed(lambda: wrapper.msmv_backward(g_plain, fd, loc, w), args.iters)
+        res["op_bwd_us_rows"] = timed(lambda: wrapper.msmv_backward(gout, fd, loc, w, rows=(T, G)), args.iters)
+        # per-stage times of the owner-computes backward, both layouts
+        dfeats = [torch.empty_like(f) for f in fd]
+        dloc, dw = torch.empty_like(loc), torch.empty_like(w)
+        ws = torch.empty(max(wrapper.backward_workspace_bytes(fd, loc, w, _lib.BWD_OWNER), 16),
+                         dtype=torch.uint8, device=dev)
+        for tag, g, rows in (("plain", g_plain, None), ("rows", gout, (T, G))):
+            for stage, bit in (("bin", _lib.BWD_STAGE_BIN), ("dfeat", _lib.BWD_STAGE_DFEAT),
+                               ("gather", _lib.BWD_STAGE_GATHER)):
+                res[f"bwd_{stage}_us_{tag}"] = timed(lambda: wrapper.msmv_backward_into(
+                    g, fd, loc, w, dfeats, dloc, dw, ws, flags=_lib.BWD_OWNER | bit, rows=rows), args.iters)
+        views = torch.round(loc[..., 2] * (N - 1)).long()
+        res["view_histogram"] = torch.bincount(views.flatten(), minlength=N).tolist()
+        res["frac_points_outside_image"] = float(((loc[..., :2] < 0) | (loc[..., :2] > 1)).any(-1).float().mean())
     alg = npts * (12 + 4 * L) * 2
     res["pack_alg_bytes"] = alg
     res["pack_fwd_GBps_fused"] = alg / res["pack_fwd_us_fused"] / 1e3
