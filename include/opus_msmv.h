@@ -169,6 +169,17 @@ int opus_msmv_project_pack_backward(const float *dloc, const float *dweights,
                                     float image_h, float image_w, float eps,
                                     float *dsample_points, float *dscale_weights, void *stream);
 
+/*
+ * Producer-side re-layout of one feature level: what the decoder does before its first layer,
+ *   feat.reshape(B,T,N,G,C,H,W).permute(0,1,3,2,5,6,4).reshape(B*T*G,N,H,W,C).contiguous()
+ * (models/opus_transformer.py:113-126, MSMV_CUDA branch), as one tiled transpose.
+ *   inverse == 0: src [B, T*N, G*C, H, W] (backbone / FPN layout) -> dst [B*T*G, N, H, W, C]
+ *   inverse != 0: src [B*T*G, N, H, W, C] (e.g. d feats of the op)  -> dst [B, T*N, G*C, H, W]
+ * src and dst must not overlap.
+ */
+int opus_msmv_relayout(const float *src, float *dst, int B, int T, int N, int G, int C, int H, int W,
+                       int inverse, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,8 @@ SYMBOLS = {
     "opus_msmv_project_pack_backward": (ctypes.c_int, [
         ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_float] * 3
         + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "opus_msmv_relayout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8
+                           + [ctypes.c_void_p]),
 }
 
 _lib = None

@@ -311,4 +311,21 @@ int opus_msmv_project_pack_backward(const float *dloc, const float *dweights,
                ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
 }
 
+int opus_msmv_relayout(const float *src, float *dst, int B, int T, int N, int G, int C, int H, int W,
+                       int inverse, void *stream)
+{
+    if (B < 0 || T < 1 || N < 1 || G < 1 || C < 1 || H < 1 || W < 1)
+        return OPUS_MSMV_EINVAL_DIMS;
+    if ((long long)H * W > INT_MAX / 64 || (long long)T * N * G > INT_MAX)
+        return OPUS_MSMV_ETOOLARGE;
+    if (B == 0)
+        return OPUS_MSMV_OK;
+    if (!src || !dst)
+        return OPUS_MSMV_EINVAL_PTR;
+    const hipError_t e = msmv_launch_relayout(src, dst, B, T, N, G, C, H, W, inverse != 0, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue)
+        return OPUS_MSMV_ETOOLARGE;
+    return e == hipSuccess ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
+}
+
 }  // extern "C"

@@ -25,3 +25,7 @@ hipError_t msmv_launch_project_pack_backward(const float *dloc, const float *dw,
                                              int B, int Q, int T, int G, int P, int L, int N,
                                              float image_h, float image_w, float eps,
                                              float *dpts, float *dsw, hipStream_t s);
+
+// Producer-side re-layout (msmv_relayout.hip): [B,T*N,G*C,H,W] <-> [B*T*G,N,H,W,C].
+hipError_t msmv_launch_relayout(const float *src, float *dst, int B, int T, int N, int G, int C, int H, int W,
+                                bool inverse, hipStream_t s);

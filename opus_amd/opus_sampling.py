@@ -25,10 +25,11 @@ from . import _lib
 from .csrc.wrapper import msmv_sampling, msmv_sampling_rows
 
 
-def relayout_features(mlvl_feats, num_frames, num_views, num_groups):
+def relayout_features_torch(mlvl_feats, num_frames, num_views, num_groups):
     """[B, T*N, G*C, H, W] per level -> [B*T*G, N, H, W, C] contiguous (channel-last).
 
-    Restates models/opus_transformer.py:113-121: channel index = g*C + c, image index = t*N + n.
+    Restates models/opus_transformer.py:113-121 as the reference writes it (reshape, permute,
+    contiguous): channel index = g*C + c, image index = t*N + n.
     """
     out = []
     for feat in mlvl_feats:
@@ -39,6 +40,46 @@ def relayout_features(mlvl_feats, num_frames, num_views, num_groups):
         feat = feat.reshape(B, T, N, G, C, H, W).permute(0, 1, 3, 2, 5, 6, 4)
         out.append(feat.reshape(B * T * G, N, H, W, C).contiguous())
     return out
+
+
+class _Relayout(torch.autograd.Function):
+    """opus_msmv_relayout behind autograd: a tiled transpose forward, its inverse backward."""
+
+    @staticmethod
+    def forward(ctx, feat, T, N, G):
+        if not feat.is_cuda:
+            raise RuntimeError("relayout_features runs on the GPU only; "
+                               "relayout_features_torch is the tensor-op statement of it")
+        B, TN, GC, H, W = feat.shape
+        assert TN == T * N and GC % G == 0
+        C = GC // G
+        src = feat.contiguous().float()
+        dst = torch.empty((B * T * G, N, H, W, C), dtype=torch.float32, device=feat.device)
+        ctx.dims = (B, T, N, G, C, H, W)
+        _Relayout._run(src, dst, ctx.dims, 0)
+        return dst
+
+    @staticmethod
+    def backward(ctx, grad):
+        B, T, N, G, C, H, W = ctx.dims
+        src = grad.contiguous().float()
+        dst = torch.empty((B, T * N, G * C, H, W), dtype=torch.float32, device=grad.device)
+        _Relayout._run(src, dst, ctx.dims, 1)
+        return dst, None, None, None
+
+    @staticmethod
+    def _run(src, dst, dims, inverse):
+        lib = _lib.load()
+        with torch.cuda.device(src.device):
+            _lib.check(lib.opus_msmv_relayout(
+                _vp(src), _vp(dst), *dims, inverse,
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "opus_msmv_relayout")
+
+
+def relayout_features(mlvl_feats, num_frames, num_views, num_groups):
+    """Same result as ``relayout_features_torch`` from one tiled-transpose launch per level
+    (and its inverse for the gradient)."""
+    return [_Relayout.apply(f, num_frames, num_views, num_groups) for f in mlvl_feats]
 
 
 def project_and_pack_torch(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):

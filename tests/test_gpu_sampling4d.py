@@ -229,3 +229,49 @@ def test_row_mode_full_size(ops):
             assert_close(a.cpu().numpy(), b.cpu().numpy(), GRAD_RTOL, f"P{P} dfeat{i}")
         assert_close(dl_r.cpu().numpy(), dl_p.cpu().numpy(), 1e-5, f"P{P} dloc")
         assert_close(dw_r.cpu().numpy(), dw_p.cpu().numpy(), 1e-5, f"P{P} dw")
+
+
+# ---------------------------------------------------------------- producer-side re-layout
+RELAYOUT_CASES = [
+    # B, T, N, G, C, H, W
+    (1, 2, 6, 4, 64, 16, 44),      # real level 2 (S = 704 = 11 tiles)
+    (1, 1, 2, 2, 64, 8, 22),       # real level 3 (S = 176: a ragged last tile)
+    (2, 3, 2, 2, 8, 3, 5),         # tiny, C < tile, S odd: scalar path
+    (1, 2, 1, 3, 100, 7, 9),       # C > tile, not a multiple of it
+    (1, 1, 1, 1, 64, 1, 1),
+    (1, 2, 3, 2, 12, 4, 6),        # C % 4 == 0, S % 4 == 0 but both smaller than a tile
+]
+
+
+@pytest.mark.parametrize("case", RELAYOUT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_relayout_is_the_reference_permute(ops, case):
+    """A pure data movement: bit-exact against reshape/permute/contiguous, both directions."""
+    B, T, N, G, C, H, W = case
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    feat = torch.randn((B, T * N, G * C, H, W), generator=gen, device="cuda").requires_grad_(True)
+    ref = ops.relayout_features_torch([feat.detach()], T, N, G)[0]
+    out = ops.relayout_features([feat], T, N, G)[0]
+    assert out.shape == ref.shape and out.is_contiguous()
+    assert torch.equal(out, ref)
+    g = torch.randn(out.shape, generator=gen, device="cuda")
+    out.backward(g)
+    # the adjoint of a permutation is its inverse
+    ref_grad = g.reshape(B, T, G, N, H, W, C).permute(0, 1, 3, 2, 6, 4, 5).reshape(B, T * N, G * C, H, W)
+    assert torch.equal(feat.grad, ref_grad)
+
+
+def test_relayout_full_size_round_trip(ops):
+    """All four levels of one OPUS sample (735 MB): forward equals the permute, inverse(forward) = id."""
+    from opus_amd import _lib
+    import ctypes
+    T, N, G, C = 8, 6, 4, 64
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for H, W in REAL_LEVELS:
+        feat = torch.randn((1, T * N, G * C, H, W), generator=gen, device="cuda")
+        out = ops.relayout_features([feat], T, N, G)[0]
+        assert torch.equal(out, ops.relayout_features_torch([feat], T, N, G)[0])
+        back = torch.empty_like(feat)
+        _lib.check(_lib.load().opus_msmv_relayout(
+            ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(back.data_ptr()), 1, T, N, G, C, H, W, 1,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "relayout")
+        assert torch.equal(back, feat)

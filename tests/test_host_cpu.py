@@ -126,7 +126,7 @@ def test_relayout_features_matches_decoder_convention():
     from opus_amd import opus_sampling
     B, T, N, G, C, H, W = 2, 3, 2, 2, 4, 3, 5
     feat = torch.arange(B * T * N * G * C * H * W, dtype=torch.float32).reshape(B, T * N, G * C, H, W)
-    out = opus_sampling.relayout_features([feat], T, N, G)[0]
+    out = opus_sampling.relayout_features_torch([feat], T, N, G)[0]
     assert out.shape == (B * T * G, N, H, W, C) and out.is_contiguous()
     b, t, g, n, c, h, w = 1, 2, 1, 1, 3, 2, 4
     assert out[(b * T + t) * G + g, n, h, w, c] == feat[b, t * N + n, g * C + c, h, w]

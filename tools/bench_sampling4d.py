@@ -108,6 +108,16 @@ def main():
         views = torch.round(loc[..., 2] * (N - 1)).long()
         res["view_histogram"] = torch.bincount(views.flatten(), minlength=N).tolist()
         res["frac_points_outside_image"] = float(((loc[..., :2] < 0) | (loc[..., :2] > 1)).any(-1).float().mean())
+    # producer-side re-layout of all four levels (735 MB in, 735 MB out per sample)
+    with torch.no_grad():
+        raw = [torch.randn((B, T * N, G * C, h, w), generator=gen, device=dev) for h, w in LEVELS]
+        res["relayout_us_fused"] = timed(lambda: opus_sampling.relayout_features(raw, T, N, G), 20)
+        res["relayout_us_tensor_ops"] = timed(lambda: opus_sampling.relayout_features_torch(raw, T, N, G), 20)
+        rl_bytes = 2 * sum(r.numel() * 4 for r in raw)
+        res["relayout_bytes"] = rl_bytes
+        res["relayout_GBps_fused"] = rl_bytes / res["relayout_us_fused"] / 1e3
+        res["relayout_GBps_tensor_ops"] = rl_bytes / res["relayout_us_tensor_ops"] / 1e3
+        del raw
     alg = npts * (12 + 4 * L) * 2
     res["pack_alg_bytes"] = alg
     res["pack_fwd_GBps_fused"] = alg / res["pack_fwd_us_fused"] / 1e3
