@@ -79,6 +79,7 @@ def alg_bytes(npts, feat_bytes):
     return {
         "msmv_fwd_c64": npts * (corner + vec + small),
         "msmv_bwd_owner_dfeat": npts * (vec + small + corner) + feat_bytes,
+        "msmv_bwd_owner_dfeat(accumulate)": npts * (vec + small + corner) + 2 * feat_bytes,
         "msmv_bwd_gather_c64": npts * (corner + vec + small + small),
         "msmv_bin_sort": npts * (12 + 12 + 16),
         # whole passes, the figures the metric is quoted on
@@ -112,7 +113,10 @@ class Step:
             fn()
 
     def run(self, record=True):
-        for loc, w, g in self.sets:
+        for layer, (loc, w, g) in enumerate(self.sets):
+            # layers of one decoder sample the same feature maps: the first backward writes
+            # d feats, the others add to it (no zero-fill, no separate add pass)
+            acc = _lib.BWD_ACCUMULATE if layer else 0
             for _ in range(self.n_fwd):
                 self._timed("msmv_fwd_c64", lambda: wrapper.msmv_forward(self.feats, loc, w), record)
             if not self.do_bwd:
@@ -122,11 +126,12 @@ class Step:
                 for name, bit in (("msmv_bin_sort", _lib.BWD_STAGE_BIN),
                                   ("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT),
                                   ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
-                    self._timed(name, lambda bit=bit: wrapper.msmv_backward_into(
-                        *args, flags=_lib.BWD_OWNER | bit), record)
+                    self._timed(name if not (acc and bit == _lib.BWD_STAGE_DFEAT) else name + "(accumulate)",
+                                lambda bit=bit: wrapper.msmv_backward_into(
+                                    *args, flags=_lib.BWD_OWNER | bit | acc), record)
             else:
-                self._timed("msmv_bwd_atomic(+clear)", lambda: wrapper.msmv_backward_into(
-                    *args, flags=_lib.BWD_ATOMIC), record)
+                self._timed("msmv_bwd_atomic(accumulate)" if acc else "msmv_bwd_atomic(+clear)",
+                            lambda: wrapper.msmv_backward_into(*args, flags=_lib.BWD_ATOMIC | acc), record)
 
     def kernel_ms(self):
         per = {}

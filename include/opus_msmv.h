@@ -53,8 +53,11 @@ enum {
     OPUS_MSMV_BWD_ATOMIC = 1,    /* wave-reduced dloc/dw + fp32 atomics into d feats (zero-filled first) */
     OPUS_MSMV_BWD_OWNER = 2      /* every d-feat tile is accumulated in LDS by one workgroup: no atomics, no zero-fill */
 };
-/* OR-ed into `flags`: do not clear d feats first, add onto their current contents
- * (atomic algorithm only).  The reference always clears (msmv_sampling.cpp:244-247). */
+/* OR-ed into `flags`: add onto the current contents of d feats instead of overwriting them
+ * (either algorithm; d loc and d weights are still overwritten).  For a stack of decoder
+ * layers that sample the same feature maps: the first layer's backward writes d feats, the
+ * others accumulate, and no zero-fill or separate add ever touches the 735 MB per sample.
+ * The reference always clears and lets autograd add (msmv_sampling.cpp:244-247). */
 #define OPUS_MSMV_BWD_ACCUMULATE 0x10
 /* OR-ed into `flags` (owner algorithm only): run just the named stage(s) of the backward,
  * so that a profiler or benchmark can time each kernel with events of its own.  The stages

@@ -167,7 +167,7 @@ int opus_msmv_forward_rows(int L, const float *const *feats, const int *hw,
 size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int P, int flags)
 {
     const int algo = flags & 0xF;
-    if (algo == OPUS_MSMV_BWD_ATOMIC || (flags & OPUS_MSMV_BWD_ACCUMULATE))
+    if (algo == OPUS_MSMV_BWD_ATOMIC)
         return 0;
     if (L < 1 || B < 0 || N < 1 || Q < 0 || P < 1)
         return 0;
@@ -197,8 +197,6 @@ static int backward_impl(int L, const float *grad_out, const float *const *feats
         return OPUS_MSMV_EINVAL_FLAGS;
     if (stage_bits && algo != OPUS_MSMV_BWD_OWNER)
         return OPUS_MSMV_EINVAL_FLAGS;
-    if (accumulate && algo == OPUS_MSMV_BWD_OWNER)
-        return OPUS_MSMV_EINVAL_FLAGS;
     if (!feats || !dfeats)
         return OPUS_MSMV_EINVAL_PTR;
     for (int l = 0; l < L; ++l) {
@@ -222,7 +220,7 @@ static int backward_impl(int L, const float *grad_out, const float *const *feats
         if (!owner_applicable(a, grad_out))
             return OPUS_MSMV_EINVAL_FLAGS;
         use_owner = true;
-    } else if (algo == OPUS_MSMV_BWD_ATOMIC || accumulate) {
+    } else if (algo == OPUS_MSMV_BWD_ATOMIC) {
         use_owner = false;
     } else {
         use_owner = owner_applicable(a, grad_out) != 0;
@@ -233,7 +231,7 @@ static int backward_impl(int L, const float *grad_out, const float *const *feats
         const size_t need = msmv_backward_owner_workspace(B, N, Q, P);
         if (!workspace || workspace_bytes < need || !aligned16(workspace))
             return OPUS_MSMV_EWORKSPACE;
-        e = msmv_launch_backward_owner(a, workspace, (hipStream_t)stream, stage_bits ? stage_bits >> 8 : 7);
+        e = msmv_launch_backward_owner(a, workspace, (hipStream_t)stream, stage_bits ? stage_bits >> 8 : 7, accumulate);
     } else {
         e = msmv_launch_backward_atomic(a, (hipStream_t)stream, accumulate);
     }

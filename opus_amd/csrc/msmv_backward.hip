@@ -361,7 +361,10 @@ struct OwnHit {
     float cw1, cw2, cw3, cw4;        // corner weight * scale weight (0 for a corner outside the patch)
 };
 
-template <int PT>
+// ACC: add the patch to what d feat already holds instead of overwriting it (one decoder
+// layer after another accumulating into one buffer); a patch that no point reaches is then
+// left alone.
+template <int PT, bool ACC>
 __global__ void __launch_bounds__(OWN_THREADS)
 msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 {
@@ -398,6 +401,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     const int nrow = min(PATCH_H, H - r0), ncol = min(PATCH_W, W - c0);
 
     msmv_f32x16 acc0 = {}, acc1 = {};                        // even / odd channels
+    [[maybe_unused]] bool any_hit = false;
 
     // ---- the bins that can reach this patch: one segment of the sorted entries per y-band
     // (all of them adjacent, i.e. one segment, when every x-band is wanted)
@@ -487,6 +491,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
             hits = 0;
 #endif
             const int nh = __popcll(hits);
+            if constexpr (ACC)
+                any_hit = any_hit || nh > 0;
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
             for (int qbase = 0; qbase < nh; qbase += OWN_QCAP) {
@@ -573,12 +579,35 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 #ifdef MSMV_ABL_NOSTORE
     if (nrow < 0)
 #endif
+    if constexpr (ACC) {
+        if (!any_hit)
+            return;                                          // wave-uniform
+        // all 16 loads first (clamped to the patch's first pixel where the patch is ragged, so
+        // that no branch separates them), then the adds and stores
+        float2 old[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int pr = i / PATCH_W, pc = i % PATCH_W;
-        if (pr < nrow && pc < ncol)
-            *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) = make_float2(acc0[r], acc1[r]);
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int pr = i / PATCH_W, pc = i % PATCH_W;
+            const bool in = pr < nrow && pc < ncol;
+            old[r] = *reinterpret_cast<const float2 *>(dst + (in ? ((size_t)pr * W + pc) * 64 : 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int pr = i / PATCH_W, pc = i % PATCH_W;
+            if (pr < nrow && pc < ncol)
+                *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) =
+                    make_float2(old[r].x + acc0[r], old[r].y + acc1[r]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int pr = i / PATCH_W, pc = i % PATCH_W;
+            if (pr < nrow && pc < ncol)
+                *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) = make_float2(acc0[r], acc1[r]);
+        }
     }
 }
 
@@ -809,7 +838,19 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
     return owner_ws_header_bytes(B, N) + (size_t)B * Q * P * sizeof(BinEntry);
 }
 
-hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages)
+template <bool ACC>
+static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const MsmvArgs &a, const OwnerWs &ws,
+                               const OwnerGeom &geo)
+{
+    switch (pt) {
+    case 1: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, ACC>), grid, block, 0, s, a, ws, geo); break;
+    case 2: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, ACC>), grid, block, 0, s, a, ws, geo); break;
+    case 4: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<4, ACC>), grid, block, 0, s, a, ws, geo); break;
+    default: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<0, ACC>), grid, block, 0, s, a, ws, geo); break;
+    }
+}
+
+hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate)
 {
     OwnerWs ws;
     ws.keys = a.N * BIN_PER_VIEW;
@@ -849,12 +890,12 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     const long long ntiles = (long long)geo.tiles_per_b * a.B;
     const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
     // in row mode the entries carry grad_out rows, which is exactly the P = 1 addressing
-    switch ((stages & 2) ? (a.rows ? 1 : a.P) : -1) {
-    case -1: break;
-    case 1: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<1>, grid, block, 0, s, a, ws, geo); break;
-    case 2: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<2>, grid, block, 0, s, a, ws, geo); break;
-    case 4: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<4>, grid, block, 0, s, a, ws, geo); break;
-    default: hipLaunchKernelGGL(msmv_bwd_owner_dfeat<0>, grid, block, 0, s, a, ws, geo); break;
+    if (stages & 2) {
+        const int pt = a.rows ? 1 : a.P;
+        if (accumulate)
+            launch_owner_dfeat<true>(pt, grid, block, s, a, ws, geo);
+        else
+            launch_owner_dfeat<false>(pt, grid, block, s, a, ws, geo);
     }
     if ((e = hipGetLastError()) != hipSuccess)
         return e;

@@ -13,7 +13,7 @@ hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool ac
 bool msmv_backward_owner_supported(const MsmvArgs &a);
 size_t msmv_backward_owner_workspace(int B, int N, int Q, int P);
 // stages: bit 0 = bin, bit 1 = d feat tiles, bit 2 = d loc / d w gather
-hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages);
+hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate);
 
 // Caller-side fusion (msmv_project.hip): projection + view selection + packing, and its backward.
 hipError_t msmv_launch_project_pack(const float *pts, const float *sw, const float *occ2img,

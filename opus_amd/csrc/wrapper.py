@@ -189,13 +189,14 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
     _lib.check(rc, "opus_msmv_backward")
 
 
-def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None):
-    """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them."""
+def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None, out_dfeats=None):
+    """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them;
+    ``out_dfeats`` given => overwrite those buffers instead of allocating new ones."""
     flags = _BWD_ALGOS[_bwd_algo if algo is None else algo]
     if dfeats is None:
-        dfeats = [torch.empty_like(f) for f in feats]
+        dfeats = out_dfeats if out_dfeats is not None else [torch.empty_like(f) for f in feats]
     else:
-        flags = _lib.BWD_ATOMIC | _lib.BWD_ACCUMULATE
+        flags |= _lib.BWD_ACCUMULATE
     dloc = torch.empty_like(loc)
     dw = torch.empty_like(w)
     msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, flags=flags, rows=rows)
@@ -253,13 +254,86 @@ class MSMVSamplingRows(torch.autograd.Function):
         return (None, None, *dfeats, dloc, dw)
 
 
+class FeatureGradSink:
+    """One d-feat buffer per level shared by every decoder layer that samples ``mlvl_feats``.
+
+    The reference lets each of the 6 layers allocate and zero a fresh 735 MB (per sample)
+    gradient and autograd add them (msmv_sampling.cpp:244-247).  With a sink the first
+    backward that runs writes the buffers, the following ones accumulate into them
+    (OPUS_MSMV_BWD_ACCUMULATE), and the total is handed to autograd once, after the last one:
+
+        sink = FeatureGradSink(mlvl_feats)          # channel-last [B',N,H,W,C] tensors
+        for layer in layers:
+            out = msmv_sampling_rows(sink, loc, w, T, G)    # or msmv_sampling(sink, loc, w)
+
+    Ordering rests on autograd's own dependency count: every op takes the sink's scalar
+    ``token`` as an extra input and returns a zero gradient for it, so the node that releases
+    the buffers cannot run before all of them have.
+    """
+
+    def __init__(self, mlvl_feats):
+        self.feats = [f.detach() for f in mlvl_feats]
+        self.buffers = None                     # allocated by the first backward
+        self.token = _SinkOpen.apply(self, *mlvl_feats)
+
+    def __len__(self):
+        return len(self.feats)
+
+
+class _SinkOpen(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sink, *feats):
+        ctx.sink = sink
+        return torch.zeros((), dtype=torch.float32, device=feats[0].device)
+
+    @staticmethod
+    def backward(ctx, _gtoken):
+        sink = ctx.sink
+        grads = sink.buffers if sink.buffers is not None else [None] * len(sink.feats)
+        sink.buffers = None                     # a later backward (retain_graph) starts afresh
+        return (None, *grads)
+
+
+class _MSMVSamplingSink(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sink, rows, token, sampling_locations, scale_weights):
+        ctx.sink, ctx.rows = sink, rows
+        ctx.save_for_backward(sampling_locations, scale_weights)
+        return msmv_forward(sink.feats, sampling_locations, scale_weights, rows=rows)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        sink = ctx.sink
+        sampling_locations, scale_weights = ctx.saved_tensors
+        first = sink.buffers is None
+        if first:
+            sink.buffers = [torch.empty_like(f) for f in sink.feats]
+        _, dloc, dw = msmv_backward(grad_output.contiguous(), sink.feats, sampling_locations, scale_weights,
+                                    dfeats=None if first else sink.buffers, rows=ctx.rows,
+                                    out_dfeats=sink.buffers if first else None)
+        return None, None, grad_output.new_zeros(()), dloc, dw
+
+
+def _sink_or_none(mlvl_feats):
+    return mlvl_feats if isinstance(mlvl_feats, FeatureGradSink) else None
+
+
 def msmv_sampling_rows(mlvl_feats, sampling_locations, scale_weights, num_frames, num_groups):
-    """msmv_sampling + sampling_4d's un-pack: [Bs*T*G, ...] inputs -> [Bs, Q, G, T*P, C]."""
+    """msmv_sampling + sampling_4d's un-pack: [Bs*T*G, ...] inputs -> [Bs, Q, G, T*P, C].
+    ``mlvl_feats`` may be a FeatureGradSink."""
+    sink = _sink_or_none(mlvl_feats)
+    if sink is not None:
+        return _MSMVSamplingSink.apply(sink, (num_frames, num_groups), sink.token,
+                                       sampling_locations, scale_weights)
     return MSMVSamplingRows.apply(num_frames, num_groups, *mlvl_feats, sampling_locations, scale_weights)
 
 
 def msmv_sampling(mlvl_feats, sampling_locations, scale_weights):
-    """Channel-last features [B,N,H,W,C] per level -> [B,Q,C,P] (reference wrapper.py:87-93)."""
+    """Channel-last features [B,N,H,W,C] per level -> [B,Q,C,P] (reference wrapper.py:87-93).
+    ``mlvl_feats`` may be a FeatureGradSink (no counterpart in the reference)."""
+    sink = _sink_or_none(mlvl_feats)
+    if sink is not None:
+        return _MSMVSamplingSink.apply(sink, None, sink.token, sampling_locations, scale_weights)
     if len(mlvl_feats) == 4:
         return MSMVSamplingC2345.apply(*mlvl_feats, sampling_locations, scale_weights)
     if len(mlvl_feats) == 5:

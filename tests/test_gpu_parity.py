@@ -237,13 +237,23 @@ def test_non_default_stream_and_accumulate(wr, oracle):
     with torch.cuda.stream(s):
         out = wr.msmv_forward(f, l, ww)
         dfeats, dloc, dw = wr.msmv_backward(g, f, l, ww, algo="owner")
-        # accumulate a second backward onto the first: d feats double
-        wr.msmv_backward(g, f, l, ww, dfeats=dfeats)
+        # accumulate two more backwards onto the first, one per algorithm: d feats triple
+        _, dloc_a, dw_a = wr.msmv_backward(g, f, l, ww, dfeats=dfeats, algo="atomic")
+        _, dloc_o, dw_o = wr.msmv_backward(g, f, l, ww, dfeats=dfeats, algo="owner")
+        # and onto a buffer that holds something else: with 64 points most patches are reached
+        # by no point and must keep their contents
+        pre = [torch.full_like(x, 3.0) for x in f]
+        wr.msmv_backward(g, f, l, ww, dfeats=pre, algo="owner")
     s.synchronize()
-    ref_df, _, _ = oracle.backward(grad_out, feats, loc, w)
+    ref_df, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
     assert_close(out.cpu().numpy(), oracle.forward(feats, loc, w), FWD_RTOL, "forward on side stream")
     for i, d in enumerate(dfeats):
-        assert_close(d.cpu().numpy(), 2 * ref_df[i], GRAD_RTOL, f"accumulated dfeat{i}")
+        assert_close(d.cpu().numpy(), 3 * ref_df[i], GRAD_RTOL, f"accumulated dfeat{i}")
+        assert_close(pre[i].cpu().numpy(), 3.0 + ref_df[i], GRAD_RTOL, f"dfeat{i} onto a filled buffer")
+    # d loc / d w are overwritten, never accumulated
+    for dl, dww in ((dloc_a, dw_a), (dloc_o, dw_o)):
+        assert_close(dl.cpu().numpy(), ref_dloc, GRAD_RTOL, "dloc with ACCUMULATE")
+        assert_close(dww.cpu().numpy(), ref_dw, GRAD_RTOL, "dw with ACCUMULATE")
 
 
 def test_sampling_4d_matches_golden(wr):

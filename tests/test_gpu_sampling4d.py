@@ -275,3 +275,70 @@ def test_relayout_full_size_round_trip(ops):
             ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(back.data_ptr()), 1, T, N, G, C, H, W, 1,
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "relayout")
         assert torch.equal(back, feat)
+
+
+# ---------------------------------------------------------------- shared d-feat buffers
+@pytest.mark.parametrize("rows", [None, (2, 2)], ids=["plain", "rows"])
+def test_feature_grad_sink_equals_autograd_sum(ops, rows):
+    """Three layers sampling the same feature maps: one shared, accumulated d-feat buffer must
+    give what autograd's sum of three separate gradients gives; d loc / d w per layer too."""
+    from opus_amd.csrc import wrapper as wr
+    B, N, C, Q, P = 4, 6, 64, 40, 2
+    feats, _, _, _ = random_case(300, REAL_LEVELS, B, N, C, Q, P)
+    layers = [random_case(301 + i, TINY_LEVELS, B, N, 1, Q, P)[1:3] for i in range(3)]     # (loc, w) per layer
+    gen = torch.Generator(device="cuda").manual_seed(9)
+
+    def run(use_sink):
+        f = [dev(x).requires_grad_(True) for x in feats]
+        lw = [(dev(l).requires_grad_(True), dev(w).requires_grad_(True)) for l, w in layers]
+        src = wr.FeatureGradSink(f) if use_sink else f
+        total = 0
+        gen.manual_seed(9)
+        for l, w in lw:
+            out = wr.msmv_sampling(src, l, w) if rows is None else wr.msmv_sampling_rows(src, l, w, *rows)
+            total = total + (out * torch.randn(out.shape, generator=gen, device="cuda")).sum()
+        total.backward()
+        return f, lw
+
+    f_ref, lw_ref = run(False)
+    f_snk, lw_snk = run(True)
+    for i, (a, b) in enumerate(zip(f_snk, f_ref)):
+        assert a.grad is not None
+        assert_close(a.grad.cpu().numpy(), b.grad.cpu().numpy(), GRAD_RTOL, f"dfeat{i} through the sink")
+    for (la, wa), (lb, wb) in zip(lw_snk, lw_ref):
+        assert_close(la.grad.cpu().numpy(), lb.grad.cpu().numpy(), 1e-5, "dloc")
+        assert_close(wa.grad.cpu().numpy(), wb.grad.cpu().numpy(), 1e-5, "dw")
+
+
+def test_feature_grad_sink_through_relayout_and_sampling_4d(ops):
+    """Backbone-layout features -> relayout -> sink -> two sampling_4d layers: gradients reach the
+    backbone layout and equal those of the tensor-op chain."""
+    B, Q, T, G, P, N, C = 1, 24, 2, 2, 2, 6, 64
+    H, W = 256, 704
+    pts, sw, occ2img = sampling4d_case(21, B, Q, T, G, P, N)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    raw0 = [torch.randn((B, T * N, G * C, h, w), generator=gen, device="cuda") for h, w in REAL_LEVELS]
+    gouts = [torch.randn((B, Q, G, T * P, C), generator=gen, device="cuda") for _ in range(2)]
+    from opus_amd.csrc import wrapper as wr
+
+    def run(fused):
+        raw = [r.clone().requires_grad_(True) for r in raw0]
+        p = dev(pts).requires_grad_(True)
+        s_ = dev(sw).requires_grad_(True)
+        if fused:
+            f = wr.FeatureGradSink(ops.relayout_features(raw, T, N, G))
+        else:
+            f = ops.relayout_features_torch(raw, T, N, G)
+        total = 0
+        for k, g in enumerate(gouts):
+            out = ops.sampling_4d(p + 0.25 * k, f, s_, dev(occ2img), H, W, N, fused=fused)
+            total = total + (out * g).sum()
+        total.backward()
+        return raw, p, s_
+
+    raw_a, p_a, s_a = run(True)
+    raw_b, p_b, s_b = run(False)
+    for i, (a, b) in enumerate(zip(raw_a, raw_b)):
+        assert_close(a.grad.cpu().numpy(), b.grad.cpu().numpy(), GRAD_RTOL, f"d raw feat {i}")
+    assert_close(p_a.grad.cpu().numpy(), p_b.grad.cpu().numpy(), GRAD_RTOL, "d sample_points")
+    assert_close(s_a.grad.cpu().numpy(), s_b.grad.cpu().numpy(), GRAD_RTOL, "d scale_weights")

@@ -62,7 +62,8 @@ def test_argument_validation_returns_before_any_launch(lib):
     bwd = lib.opus_msmv_backward
     args = (1, null, ptrs, hw, null, null, 1, 8, 6, 1, 1, ptrs, null, null, null, 0)
     assert bwd(*args, 3, null) == -7                                           # unknown algorithm
-    assert bwd(*args, 0x12, null) == -7                                        # accumulate + owner
+    assert bwd(*args, 0x12, null) == -4                                        # accumulate + owner is legal: next check
+    assert bwd(*args, 0x20, null) == -7                                        # unknown flag bit
     assert bwd(*args, 0x101, null) == -7                                       # stage bits need owner
     assert bwd(*args, 1, null) == -4                                           # null data
     # workspace: none for the atomic algorithm, header + 32 B per point for the owner one
@@ -70,6 +71,19 @@ def test_argument_validation_returns_before_any_launch(lib):
     assert ws(4, 32, 64, 6, 4800, 2, 1) == 0
     assert ws(4, 32, 8, 6, 4800, 2, 0) == 0                                    # C != 64 -> atomic
     n = ws(4, 32, 64, 6, 4800, 2, 0)
+    assert ws(4, 32, 64, 6, 4800, 2, 0x12) == n and ws(4, 32, 64, 6, 4800, 2, 0x11) == 0   # with ACCUMULATE
+    # row mode: the batch is Bs*T*G; the re-layout and projection entry points validate too
+    assert lib.opus_msmv_forward_rows(1, ptrs, hw, null, null, 1, 0, 4, 8, 6, 1, 1, null, 0, null) == -3
+    assert lib.opus_msmv_forward_rows(1, ptrs, hw, null, null, 1, 8, 4, 8, 6, 1, 1, null, 0, null) == -4
+    assert lib.opus_msmv_forward_rows(1, ptrs, hw, null, null, 0, 8, 4, 8, 6, 5, 1, null, 0, null) == 0
+    assert lib.opus_msmv_relayout(null, null, 1, 8, 6, 4, 64, 0, 4, 0, null) == -3
+    assert lib.opus_msmv_relayout(null, null, 1, 8, 6, 4, 64, 4, 4, 0, null) == -4
+    assert lib.opus_msmv_relayout(null, null, 0, 8, 6, 4, 64, 4, 4, 0, null) == 0
+    pp = lib.opus_msmv_project_pack
+    assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 1, 256.0, 704.0, 1e-5, null, null, null) == -3   # N < 2
+    assert pp(null, null, null, 1, 4, 8, 4, 33, 4, 6, 256.0, 704.0, 1e-5, null, null, null) == -2
+    assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, null, null, null) == -4
+    assert pp(null, null, null, 1, 0, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, null, null, null) == 0
     assert n >= 32 * 4800 * 2 * 32 and n < 32 * 4800 * 2 * 32 + (1 << 20)
 
 
