@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 from opus_amd import _lib  # noqa: E402
 from opus_amd import dist as odist  # noqa: E402
+from opus_amd import opus_sampling  # noqa: E402
 from opus_amd.csrc import wrapper  # noqa: E402
 
 LEVELS = [(64, 176), (32, 88), (16, 44), (8, 22)]     # 256x704 input, strides 4..32
@@ -46,7 +47,12 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="L-fwdbwd",
                     help="{T,S,M,L}-fwd | {T,S,M,L}-fwdbwd | decoder-L (6 layers fwd+bwd) | "
-                         "train-M (6 x (2 fwd + 1 bwd) + RCCL all-reduce of a 0.3 GB gradient)")
+                         "train-M (6 x (2 fwd + 1 bwd) + RCCL all-reduce of a 0.3 GB gradient) | "
+                         "sampling4d-{T,S,M,L} (projection + op in the caller's layout, fwd+bwd)")
+    ap.add_argument("--points", default="uniform", choices=["uniform", "cameras"],
+                    help="uniform: u,v ~ U(0,1), view ~ U{0..5} (every corner in range: the byte count is "
+                         "exact); cameras: 3-D points in the occupancy range projected into a ring of 6 "
+                         "synthetic cameras x 8 ego poses (some points fall outside every image)")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU (B' = 32 * batch)")
     ap.add_argument("--bwd-algo", default="owner", choices=["owner", "atomic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,6 +75,63 @@ def make_inputs(Bp, Q, P, seed, device, n_sets=1):
     return feats, sets
 
 
+def camera_sets(Bp, Q, P, seed, device, n_sets):
+    """Caller-side inputs of sampling_4d: 3-D points in pc_range = [-40,-40,-1, 40,40,5.4]
+    (configs/opus-*: point_cloud_range), softmax scale weights, ring-of-cameras occ2img."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from procedural import synthetic_occ2img
+    T, G, N, L = 8, 4, N_VIEWS, len(LEVELS)
+    B = Bp // (T * G)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    lo = torch.tensor([-40.0, -40.0, -1.0], device=device)
+    hi = torch.tensor([40.0, 40.0, 5.4], device=device)
+    occ2img = torch.from_numpy(synthetic_occ2img(np.random.default_rng(seed), B, T, N, 256, 704)).to(device)
+    sets = []
+    for _ in range(n_sets):
+        pts = torch.rand((B, Q, T, G, P, 3), generator=gen, device=device) * (hi - lo) + lo
+        sw = torch.softmax(torch.randn((B, Q, G, T, P, L), generator=gen, device=device), -1)
+        sets.append((pts, sw, occ2img))
+    return sets
+
+
+def unique_feature_bytes(loc, n_views):
+    """Compulsory feature traffic of one pass: 256 B x the number of DISTINCT (slab, view, level,
+    pixel) corners the points touch (what an infinite cache would fetch)."""
+    Bp = loc.shape[0]
+    x, y = loc[..., 0].flatten(1), loc[..., 1].flatten(1)
+    view = torch.round(loc[..., 2].flatten(1) * (n_views - 1)).long()
+    slab = torch.arange(Bp, device=loc.device)[:, None] * n_views + view
+    total = 0
+    for H, W in LEVELS:
+        h_im, w_im = y * (H - 1), x * (W - 1)
+        ok = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+        h0, w0 = torch.floor(h_im).long(), torch.floor(w_im).long()
+        keys = []
+        for dh in (0, 1):
+            for dw_ in (0, 1):
+                hh, ww = h0 + dh, w0 + dw_
+                inside = ok & (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W)
+                keys.append(((slab * H + hh) * W + ww)[inside])
+        total += torch.unique(torch.cat(keys)).numel() * CHANNELS * 4
+    return total
+
+
+def copy_bandwidth(device, nbytes=512 << 20, reps=5):
+    """Measured device-to-device copy rate (read + write bytes per second) on this box."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def alg_bytes(npts, feat_bytes):
     """Algorithmic (no-reuse) bytes per launch of each kernel, L = 4 levels, C = 64 fp32:
     a corner vector is 256 B, 16 corners per point."""
@@ -82,6 +145,9 @@ def alg_bytes(npts, feat_bytes):
         "msmv_bwd_owner_dfeat(accumulate)": npts * (vec + small + corner) + 2 * feat_bytes,
         "msmv_bwd_gather_c64": npts * (corner + vec + small + small),
         "msmv_bin_sort": npts * (12 + 12 + 16),
+        # caller-side kernels: 12 B point + 4L B weights in, the same out
+        "msmv_project_pack": npts * (12 + 4 * L) * 2,
+        "msmv_project_pack_bwd": npts * ((12 + 4 * L) * 2 + 12 + 12),
         # whole passes, the figures the metric is quoted on
         "forward": npts * (corner + vec + small),
         "backward": npts * (vec + small + corner + corner + small) + feat_bytes,
@@ -91,10 +157,17 @@ def alg_bytes(npts, feat_bytes):
 class Step:
     """One decoder layer's forward (+ backward) with an event pair around every launch."""
 
-    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1):
+    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1, caller=None):
         self.feats, self.sets, self.do_bwd, self.n_fwd = feats, sets, do_bwd, n_fwd
         self.algo = algo
+        # caller = list of (sample_points, scale_weights, occ2img), one per set: the step then
+        # includes the projection kernels and the op runs in row mode ([B,Q,G,T*P,C] tensors)
+        self.caller = caller
+        self.rows = (8, 4) if caller else None
         loc, w, _ = sets[0]
+        if caller:
+            self.dpts = torch.empty_like(caller[0][0])
+            self.dsw = torch.empty_like(caller[0][1])
         self.dfeats = [torch.empty_like(f) for f in feats]
         self.dloc, self.dw = torch.empty_like(loc), torch.empty_like(w)
         flags = _lib.BWD_OWNER if algo == "owner" else _lib.BWD_ATOMIC
@@ -117,8 +190,13 @@ class Step:
             # layers of one decoder sample the same feature maps: the first backward writes
             # d feats, the others add to it (no zero-fill, no separate add pass)
             acc = _lib.BWD_ACCUMULATE if layer else 0
+            rows = self.rows
             for _ in range(self.n_fwd):
-                self._timed("msmv_fwd_c64", lambda: wrapper.msmv_forward(self.feats, loc, w), record)
+                if self.caller:
+                    pts, sw, occ2img = self.caller[layer]
+                    self._timed("msmv_project_pack", lambda: opus_sampling.project_pack_into(
+                        pts, sw, occ2img, 256, 704, N_VIEWS, loc, w), record)
+                self._timed("msmv_fwd_c64", lambda: wrapper.msmv_forward(self.feats, loc, w, rows=rows), record)
             if not self.do_bwd:
                 continue
             args = (g, self.feats, loc, w, self.dfeats, self.dloc, self.dw, self.ws)
@@ -128,16 +206,25 @@ class Step:
                                   ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
                     self._timed(name if not (acc and bit == _lib.BWD_STAGE_DFEAT) else name + "(accumulate)",
                                 lambda bit=bit: wrapper.msmv_backward_into(
-                                    *args, flags=_lib.BWD_OWNER | bit | acc), record)
+                                    *args, flags=_lib.BWD_OWNER | bit | acc, rows=rows), record)
             else:
                 self._timed("msmv_bwd_atomic(accumulate)" if acc else "msmv_bwd_atomic(+clear)",
-                            lambda: wrapper.msmv_backward_into(*args, flags=_lib.BWD_ATOMIC | acc), record)
+                            lambda: wrapper.msmv_backward_into(*args, flags=_lib.BWD_ATOMIC | acc, rows=rows), record)
+            if self.caller:
+                self._timed("msmv_project_pack_bwd", lambda: opus_sampling.project_pack_backward_into(
+                    self.dloc, self.dw, pts, occ2img, loc, 256, 704, N_VIEWS, self.dpts, self.dsw), record)
 
     def kernel_ms(self):
+        """name -> (mean, launches, p10, p50, p90) in ms."""
         per = {}
         for name, a, b in self.events:
             per.setdefault(name, []).append(a.elapsed_time(b))
-        return {k: (statistics.mean(v), len(v)) for k, v in per.items()}
+        out = {}
+        for k, v in per.items():
+            v = sorted(v)
+            pick = lambda f: v[min(len(v) - 1, int(f * len(v)))]      # noqa: E731
+            out[k] = (statistics.mean(v), len(v), pick(0.1), pick(0.5), pick(0.9))
+        return out
 
 
 def cpu_baseline(variant, do_bwd, slabs=8, reps=5):
@@ -204,6 +291,9 @@ def main():
         variant, do_bwd, n_layers = "L", True, 6
     elif wl == "train-M":
         variant, do_bwd, n_layers, n_fwd, allreduce_bytes = "M", True, 6, 2, 300 * 1000 * 1000
+    elif wl.startswith("sampling4d-"):
+        variant, do_bwd = wl.split("-")[1], True
+        assert variant in VARIANTS, wl
     else:
         variant, mode = wl.split("-")
         do_bwd = mode == "fwdbwd"
@@ -211,7 +301,15 @@ def main():
     Q, P = VARIANTS[variant]
     Bp = SLABS_PER_SAMPLE * args.batch
     feats, sets = make_inputs(Bp, Q, P, 1234 + rank, device, n_sets=n_layers)
-    step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd)
+    caller = None
+    if args.points == "cameras" or wl.startswith("sampling4d-"):
+        cam = camera_sets(Bp, Q, P, 1234 + rank, device, n_layers)
+        for (loc, w, g), (pts, sw, occ2img) in zip(sets, cam):
+            opus_sampling.project_pack_into(pts, sw, occ2img, 256, 704, N_VIEWS, loc, w)
+        if wl.startswith("sampling4d-"):
+            caller = cam
+            sets = [(loc, w, g.reshape(args.batch, Q, 4, 8 * P, CHANNELS)) for loc, w, g in sets]
+    step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd, caller=caller)
     npts_step = Bp * Q * P * n_layers                    # sampled points per step per rank
     feat_bytes = sum(f.numel() * 4 for f in feats)
 
@@ -245,9 +343,9 @@ def main():
         kms = step.kernel_ms()
         ab = alg_bytes(Bp * Q * P, feat_bytes)
         kernels = {}
-        for name, (ms, n) in kms.items():
-            rec = {"avg_us": ms * 1e3, "launches": n}
-            if name in ab:
+        for name, (ms, n, p10, p50, p90) in kms.items():
+            rec = {"avg_us": ms * 1e3, "launches": n, "p10_us": p10 * 1e3, "p50_us": p50 * 1e3, "p90_us": p90 * 1e3}
+            if name in ab and (args.points == "uniform" or name.startswith("msmv_project")):
                 rec["alg_bytes"] = ab[name]
                 rec["achieved_GBps"] = ab[name] / (ms * 1e-3) / 1e9
             kernels[name] = rec
@@ -262,6 +360,9 @@ def main():
                             "features re-touched by several points are served from L2 / Infinity Cache"}
         pass_bytes = (ab["forward"] * n_fwd + (ab["backward"] if do_bwd else 0)) * n_layers
         ms_per_step = elapsed / args.steps * 1e3
+        loc0 = sets[0][0]
+        outside = ((loc0[..., :2] < 0) | (loc0[..., :2] > 1)).any(-1).float().mean().item()
+        copy_gbps = copy_bandwidth(device)
         result = {
             "metric": "sampled points/sec (fwd+bwd) + % HBM roofline, OPUS-T/L shape, 1/2/4/8 GPUs",
             "value": world * npts_step * args.steps / elapsed,
@@ -271,16 +372,25 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"OPUS-{variant} sampling shape, "
+                                   f"{'projection + op in the caller layout, ' if caller else ''}"
                                    f"{'forward + backward' if do_bwd else 'forward'}"
                                    f"{', %d decoder layers' % n_layers if n_layers > 1 else ''}"
                                    f"{', 2 forwards per backward + gradient all-reduce' if wl == 'train-M' else ''}",
                        "name": wl, "Q": Q, "P": P, "slabs_per_gpu": Bp, "views": N_VIEWS,
                        "levels": LEVELS, "channels": CHANNELS,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
+                       "points": args.points if not caller else "cameras",
+                       "frac_points_outside_image": outside,
                        "parallelism": f"dp{world} (batch-parallel, no data-path collective)"},
             "roofline": roofline,
             "step_alg_GBps": pass_bytes / (ms_per_step * 1e-3) / 1e9,
             "step_alg_frac_of_peak": pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            # companions of the no-reuse figure: what an infinite cache would have to fetch, and
+            # this box's measured device-copy rate as a practical ceiling
+            "compulsory_feature_bytes_per_pass": unique_feature_bytes(loc0, N_VIEWS),
+            "gathered_feature_bytes_per_pass": Bp * Q * P * len(LEVELS) * 4 * CHANNELS * 4,
+            "device_copy_GBps_measured": copy_gbps,
+            "step_alg_frac_of_measured_copy": pass_bytes / (ms_per_step * 1e-3) / 1e9 / copy_gbps,
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -100,11 +100,19 @@ struct BinEntry {       // 32 bytes: everything the d-feat pass needs about a po
     float w[5];         // the point's scale weights (L <= 5; unused slots are 0)
 };
 
-constexpr int BIN_YB = 16;               // y-bands per (batch, view)
-constexpr int BIN_XB = 8;                // x-bands per y-band
+// (8, 32) measured best of (16,8) (16,16) (16,32) (32,8) (8,32): a patch is 8 pixels wide, so
+// narrow x-bands cut the entries a wave scans in vain; every y-band is one more segment to walk
+#ifndef MSMV_BIN_YB
+#define MSMV_BIN_YB 8
+#endif
+#ifndef MSMV_BIN_XB
+#define MSMV_BIN_XB 32
+#endif
+constexpr int BIN_YB = MSMV_BIN_YB;      // y-bands per (batch, view)
+constexpr int BIN_XB = MSMV_BIN_XB;      // x-bands per y-band
 constexpr int BIN_PER_VIEW = BIN_YB * BIN_XB;
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_MAX_KEYS = 2048;       // N * BIN_PER_VIEW must not exceed this
+constexpr int BIN_MAX_KEYS = 4096;       // N * BIN_PER_VIEW must not exceed this (N <= 16)
 
 // workspace layout:
 //   [ counts: B*keys ints ][ cursors: B*keys ints ]   cleared by a memset node every call
@@ -282,10 +290,21 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 // A wave scans only the bins whose bands can reach its rows / columns; lanes that find a
 // hit (a point with a corner in the patch) write a 32-byte record into a small per-wave LDS
 // queue; the wave then consumes the queue two records at a time (one per half-wave).
+//
+// A wave applies its hits one after the other and keeps only two groups of gradient loads in
+// flight, so its run time grows with the hits of its patch: a patch of a coarse level (or of a
+// crowded image region) collects hundreds of hits where a fine one collects a handful, and
+// those few long waves would finish last.  A level whose patches expect many hits is
+// therefore worked on by K = 2, 4 or 8 waves per patch: wave k of the K takes entries
+// k, k + K, k + 2K, ... of the patch's bins, and the K partial accumulators are summed through
+// LDS (log2 K rounds) before the store.  A workgroup is always 8 waves = 8 / K patches.
 constexpr int PATCH_H = 4, PATCH_W = 8;
 static_assert(PATCH_H * PATCH_W == 32, "a patch is the M = 32 dimension of the MFMA tile");
-constexpr int OWN_WAVES = 8;                     // patches per workgroup
+constexpr int OWN_WAVES = 8;                     // waves per workgroup; at most all of them share one patch
 constexpr int OWN_THREADS = OWN_WAVES * 64;
+#ifndef MSMV_OWN_SPLIT_HITS
+#define MSMV_OWN_SPLIT_HITS 64                   // expected hits per wave above which a level's patches are shared
+#endif
 constexpr int OWN_QCAP = 16;             // hit records a wave queues before consuming them
 constexpr int OWN_GROUP = 2;             // record pairs per group; two groups' gradient loads are in flight
 
@@ -293,6 +312,7 @@ struct OwnerGeom {
     int tiles_per_level[MSMV_MAX_LEVELS];   // workgroups per (batch, view) slab of the level
     int patch_cols[MSMV_MAX_LEVELS];        // patches per row of patches: ceil(W / PATCH_W)
     int patches[MSMV_MAX_LEVELS];           // patches per slab: ceil(H / PATCH_H) * patch_cols
+    int split_log2[MSMV_MAX_LEVELS];        // log2 K: waves per patch at the level (K in {1,2,4,8})
     int tiles_per_b;                         // N * sum over levels
 };
 
@@ -365,12 +385,13 @@ struct OwnHit {
 // layer after another accumulating into one buffer); a patch that no point reaches is then
 // left alone.
 template <int PT, bool ACC>
-__global__ void __launch_bounds__(OWN_THREADS)
+__global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 {
     constexpr int GP = PT == 4 ? 1 : OWN_GROUP;      // P = 4 fetches 32 B per lane and record
     static_assert(OWN_QCAP % (2 * GP) == 0 && OWN_QCAP <= 64, "queue is consumed in whole groups");
     __shared__ float4 queue_all[OWN_WAVES][OWN_QCAP * 2];      // 2 float4 per record
+    __shared__ float red[OWN_WAVES / 2][32 * 64];              // partial tiles on their way to another wave
 
     const int lane = threadIdx.x & 63;
     const int l32 = lane & 31;
@@ -378,7 +399,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *queue = queue_all[wave];
 
-    // ---- which run of pixels: logical order [b][level, coarse first][view][tile][wave]
+    // ---- which patch: logical order [b][level, coarse first][view][tile][wave / K]
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
     const int b = id / geo.tiles_per_b;
     id -= b * geo.tiles_per_b;
@@ -391,11 +412,14 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     }
     const int view = id / geo.tiles_per_level[l];
     const int tile_idx = id - view * geo.tiles_per_level[l];
+    const int klog = geo.split_log2[l];
+    const int K = 1 << klog;                                 // waves sharing a patch
+    const int sub = wave & (K - 1);                          // this wave's share: entries sub, sub + K, ...
+    const int patch_raw = tile_idx * (OWN_WAVES >> klog) + (wave >> klog);
+    const bool idle = patch_raw >= geo.patches[l];           // past the slab's last patch: takes part in
+    const int patch = idle ? 0 : patch_raw;                  // the barriers below, stores nothing
     const int H = a.lvl[l].H, W = a.lvl[l].W;
     const int S = H * W;
-    const int patch = tile_idx * OWN_WAVES + wave;           // this wave's patch, row-major
-    if (patch >= geo.patches[l])
-        return;                                              // wave-uniform; no barriers below
     const int prow = patch / geo.patch_cols[l];
     const int r0 = prow * PATCH_H, c0 = (patch - prow * geo.patch_cols[l]) * PATCH_W;
     const int nrow = min(PATCH_H, H - r0), ncol = min(PATCH_W, W - c0);
@@ -409,7 +433,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     msmv_band_range<BIN_YB>(r0, r0 + nrow - 1, H, yb_lo, yb_hi);
     msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, xb_lo, xb_hi);
     const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
-    const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB = 16
+    const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB
     const int *off = ws.offsets + (size_t)b * (ws.keys + 1) + view * BIN_PER_VIEW;
     const float4 *list = reinterpret_cast<const float4 *>(ws.entries + (size_t)b * a.qp);
 
@@ -431,11 +455,13 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     }
     const int seg_excl = incl - seg_len;
     const int seg_delta = seg_begin - seg_excl;
-    const int total = __builtin_amdgcn_readlane(incl, nseg - 1);
+    const int total = idle ? 0 : __builtin_amdgcn_readlane(incl, nseg - 1);
 
-    // entry index of virtual entry v (clamped into range so that every lane loads something)
-    auto entry_index = [&](int v0) {
-        const int v = min(v0 + lane, total - 1);
+    // This wave's j-th entry is virtual entry j*K + sub of the concatenated segments.
+    // entry_index: its index in the entry array for j = j0 + lane (clamped into range so that
+    // every lane loads something).
+    auto entry_index = [&](int j0) {
+        const int v = min(((j0 + lane) << klog) + sub, total - 1);
         int idx = v + __builtin_amdgcn_readlane(seg_delta, 0);
         for (int sgm = 1; sgm < nseg; ++sgm) {
             const int cs = __builtin_amdgcn_readlane(seg_excl, sgm);
@@ -449,9 +475,9 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
         e0 = list[(size_t)idx * 2];
         wl = reinterpret_cast<const float *>(list + (size_t)idx * 2)[3 + l];
     };
-    auto scan = [&](int v0, const float4 &e0, float wl) {
+    auto scan = [&](int j0, const float4 &e0, float wl) {
         OwnHit h;
-        const bool valid = v0 + lane < total;
+        const bool valid = ((j0 + lane) << klog) + sub < total;
         h.pt = __float_as_int(e0.x);
         const MsmvTap t = msmv_make_tap(e0.y, e0.z, H, W, valid);
         // corner rows / columns relative to the patch; the unsigned compares also reject the
@@ -476,14 +502,14 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 #ifdef MSMV_ABL_NOSCAN
     if (false)
 #endif
-    if (total > 0) {
+    if (sub < total) {
         float4 e0;
         float wl;
         load_entry(entry_index(0), e0, wl);
-        for (int v0 = 0; v0 < total; v0 += 64) {
-            const OwnHit h = scan(v0, e0, wl);
-            if (v0 + 64 < total)                               // next chunk's entries, in flight
-                load_entry(entry_index(v0 + 64), e0, wl);      // while this chunk's hits are applied
+        for (int j0 = 0; (j0 << klog) + sub < total; j0 += 64) {
+            const OwnHit h = scan(j0, e0, wl);
+            if (((j0 + 64) << klog) + sub < total)             // next chunk's entries, in flight
+                load_entry(entry_index(j0 + 64), e0, wl);      // while this chunk's hits are applied
 
             unsigned long long hits = __ballot(h.hit);
 #ifdef MSMV_ABL_NOHITS
@@ -568,6 +594,36 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 #undef MSMV_OWN_MFMA
             }
         }
+    }
+
+    // ---- K > 1: sum the K partial tiles of a patch, halving the live waves per round.  The
+    // round count is the workgroup's (one level, one K): every wave reaches every barrier.
+    for (int stride = K >> 1; stride >= 1; stride >>= 1) {
+        const int slot = (wave >> klog) * (K >> 1) + (sub & (stride - 1));   // < OWN_WAVES / 2, one per pair
+        if (sub >= stride && sub < 2 * stride) {
+            float *dstw = red[slot] + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dstw[r * 64] = acc0[r];
+                dstw[(16 + r) * 64] = acc1[r];
+            }
+        }
+        __syncthreads();
+        if (sub < stride) {
+            const float *srcw = red[slot] + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] += srcw[r * 64];
+                acc1[r] += srcw[(16 + r) * 64];
+            }
+        }
+        __syncthreads();
+    }
+    if (sub != 0 || idle)
+        return;
+    if constexpr (ACC) {
+        if (K > 1)
+            any_hit = total > 0;         // (a patch whose bins hold entries but no hit adds zeros)
     }
 
     // ---- store the patch once.  Accumulator register r of lane (half, l32) is patch pixel
@@ -839,8 +895,8 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
 }
 
 template <bool ACC>
-static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const MsmvArgs &a, const OwnerWs &ws,
-                               const OwnerGeom &geo)
+static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const MsmvArgs &a,
+                               const OwnerWs &ws, const OwnerGeom &geo)
 {
     switch (pt) {
     case 1: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, ACC>), grid, block, 0, s, a, ws, geo); break;
@@ -878,24 +934,34 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
             return e;
     }
 
-    OwnerGeom geo = {};
-    int per_view = 0;
-    for (int l = 0; l < a.L; ++l) {
-        geo.patch_cols[l] = (a.lvl[l].W + PATCH_W - 1) / PATCH_W;
-        geo.patches[l] = ((a.lvl[l].H + PATCH_H - 1) / PATCH_H) * geo.patch_cols[l];
-        geo.tiles_per_level[l] = (geo.patches[l] + OWN_WAVES - 1) / OWN_WAVES;
-        per_view += geo.tiles_per_level[l];
-    }
-    geo.tiles_per_b = per_view * a.N;
-    const long long ntiles = (long long)geo.tiles_per_b * a.B;
-    const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
-    // in row mode the entries carry grad_out rows, which is exactly the P = 1 addressing
     if (stages & 2) {
-        const int pt = a.rows ? 1 : a.P;
-        if (accumulate)
-            launch_owner_dfeat<true>(pt, grid, block, s, a, ws, geo);
-        else
-            launch_owner_dfeat<false>(pt, grid, block, s, a, ws, geo);
+        OwnerGeom geo = {};
+        int per_view = 0;
+        for (int l = 0; l < a.L; ++l) {
+            geo.patch_cols[l] = (a.lvl[l].W + PATCH_W - 1) / PATCH_W;
+            geo.patches[l] = ((a.lvl[l].H + PATCH_H - 1) / PATCH_H) * geo.patch_cols[l];
+            // a point touches ~1.4 patches of a level: expected hits per patch, uniform points
+            const double expect = 1.4 * (double)a.qp / ((double)a.N * geo.patches[l]);
+            int klog = 0;
+            while (klog < 3 && expect > (double)MSMV_OWN_SPLIT_HITS * (1 << klog))
+                ++klog;
+            geo.split_log2[l] = klog;
+            const int per_wg = OWN_WAVES >> klog;
+            geo.tiles_per_level[l] = (geo.patches[l] + per_wg - 1) / per_wg;
+            per_view += geo.tiles_per_level[l];
+        }
+        geo.tiles_per_b = per_view * a.N;
+        const long long ntiles = (long long)geo.tiles_per_b * a.B;
+        if (ntiles > 0x7FFFFFFFll)
+            return hipErrorInvalidValue;
+        if (ntiles > 0) {
+            const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
+            const int pt = a.rows ? 1 : a.P;
+            if (accumulate)
+                launch_owner_dfeat<true>(pt, grid, block, s, a, ws, geo);
+            else
+                launch_owner_dfeat<false>(pt, grid, block, s, a, ws, geo);
+        }
     }
     if ((e = hipGetLastError()) != hipSuccess)
         return e;

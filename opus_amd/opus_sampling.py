@@ -173,6 +173,37 @@ class _ProjectPack(torch.autograd.Function):
         return dpts, dsw, None, None, None, None, None
 
 
+def project_pack_into(sample_points, scale_weights, occ2img, image_h, image_w, num_views, loc, weights,
+                      eps=1e-5):
+    """Raw opus_msmv_project_pack into caller-owned ``loc`` / ``weights`` (no autograd, no
+    allocation): for benchmarks and callers that manage their own buffers."""
+    B, Q, T, G, P, _ = sample_points.shape
+    L = scale_weights.shape[-1]
+    assert loc.shape == (B * T * G, Q, P, 3) and weights.shape == (B * G * T, Q, P, L)
+    for t in (sample_points, scale_weights, occ2img, loc, weights):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+    with torch.cuda.device(loc.device):
+        _lib.check(_lib.load().opus_msmv_project_pack(
+            _vp(sample_points), _vp(scale_weights), _vp(occ2img), B, Q, T, G, P, L, int(num_views),
+            float(image_h), float(image_w), float(eps), _vp(loc), _vp(weights),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "opus_msmv_project_pack")
+
+
+def project_pack_backward_into(dloc, dweights, sample_points, occ2img, loc, image_h, image_w, num_views,
+                               dsample_points, dscale_weights, eps=1e-5):
+    """Raw opus_msmv_project_pack_backward into caller-owned gradient buffers."""
+    B, Q, T, G, P, _ = sample_points.shape
+    L = dweights.shape[-1]
+    assert dsample_points.shape == sample_points.shape and dscale_weights.shape == (B, Q, G, T, P, L)
+    for t in (dloc, dweights, sample_points, occ2img, loc, dsample_points, dscale_weights):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+    with torch.cuda.device(loc.device):
+        _lib.check(_lib.load().opus_msmv_project_pack_backward(
+            _vp(dloc), _vp(dweights), _vp(sample_points), _vp(occ2img), _vp(loc), B, Q, T, G, P, L,
+            int(num_views), float(image_h), float(image_w), float(eps), _vp(dsample_points), _vp(dscale_weights),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "opus_msmv_project_pack_backward")
+
+
 def project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
     """Same result as ``project_and_pack_torch`` from one HIP kernel (and one for the
     backward): (loc [B*T*G, Q, P, 3], weights [B*G*T, Q, P, L]).  occ2img gets no gradient

@@ -135,6 +135,21 @@ def test_hot_spot_thousands_of_points_in_one_patch(wr, oracle):
     _check_all(wr, oracle, feats, loc, w, grad_out)
 
 
+def test_patches_shared_by_several_waves(wr, oracle):
+    """Many points on small levels: the owner kernel puts 2, 4 or 8 waves on one patch (each
+    takes every K-th bin entry) and sums their partial tiles; includes ragged patches, slabs
+    whose patch count is not a multiple of the patches per workgroup, and accumulate mode."""
+    for levels, Q in (([(8, 22), (4, 11), (2, 6), (1, 3)], 2000), ([(16, 44), (8, 22), (5, 13), (3, 3)], 1200)):
+        feats, loc, w, grad_out = random_case(60 + Q, levels, B=2, N=6, C=64, Q=Q, P=2, oob_frac=0.1)
+        _check_all(wr, oracle, feats, loc, w, grad_out)
+    f = [dev(x) for x in feats]
+    pre = [torch.full_like(x, -2.0) for x in f]
+    wr.msmv_backward(dev(grad_out), f, dev(loc), dev(w), dfeats=pre, algo="owner")
+    ref_df, _, _ = oracle.backward(grad_out, feats, loc, w)
+    for i, d in enumerate(pre):
+        assert_close(d.cpu().numpy(), ref_df[i] - 2.0, GRAD_RTOL, f"shared patches, accumulate, dfeat{i}")
+
+
 def test_odd_level_sizes_and_partial_patches(wr, oracle):
     levels = [(13, 31), (5, 7), (3, 9), (1, 1)]
     for P in (1, 2, 4, 5):
