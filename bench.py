@@ -16,6 +16,7 @@ from the closed forms below), and - at N = 1 - the CPU baseline (the grid_sample
 formulation of oracle/torch_ref.py on the host cores, on a bounded sample).
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -330,6 +331,10 @@ def main():
                     dist.all_reduce(b)
             torch.cuda.current_stream().wait_stream(comm_stream)
 
+    # a generational collection of the interpreter's heap (tens of ms with torch loaded) inside
+    # the timed loop would stall the launches of one step and be billed to the GPU path
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         one_step(False)
     odist.fence(dist, device)
@@ -338,6 +343,7 @@ def main():
         one_step(True)
     odist.fence(dist, device)
     elapsed = odist.max_over_ranks(time.perf_counter() - t0, dist, device)
+    gc.enable()
 
     if rank == 0:
         kms = step.kernel_ms()

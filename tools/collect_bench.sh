@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: the bench.py lines committed under profiles/ (copied from gpurun_out/<tag>/).
+#   gpurun -- 'bash tools/collect_bench.sh r01'
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG/bench
+mkdir -p "$O"
+cd "$R"
+run() { # name, args...
+    local name=$1; shift
+    timeout -k 10 300 python3 bench.py "$@" > "$O/${TAG}_bench_$name.json" 2> "$O/$name.err" || { echo "FAILED $name"; tail -3 "$O/$name.err"; exit 1; }
+    echo "done $name"
+}
+run L --steps 50 --warmup 10
+for v in T S M; do run $v-fwdbwd --workload $v-fwdbwd --no-cpu-baseline; done
+run T-fwd --workload T-fwd --no-cpu-baseline
+run L-fwd --workload L-fwd --no-cpu-baseline
+run T-fwd_batch8 --workload T-fwd --batch 8 --no-cpu-baseline
+run L_batch8 --batch 8 --steps 20 --no-cpu-baseline
+run L_atomic --bwd-algo atomic --steps 20 --no-cpu-baseline
+run L_cameras --points cameras --no-cpu-baseline
+run decoder-L --workload decoder-L --steps 20 --no-cpu-baseline
+run sampling4d-L --workload sampling4d-L --no-cpu-baseline
+run sampling4d-T --workload sampling4d-T --no-cpu-baseline
+timeout -k 10 200 python3 tools/bench_sampling4d.py > "$O/${TAG}_sampling4d_fusion.json" 2> "$O/fusion.err" || exit 1
+echo "bench lines under $O"
