@@ -317,6 +317,17 @@ struct OwnerGeom {
 };
 
 typedef float msmv_f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) const void *msmv_gptr_t;
+typedef __attribute__((address_space(3))) void *msmv_lptr_t;
+#ifndef MSMV_OWN_STAGED
+#define MSMV_OWN_STAGED 1
+#endif
+#ifndef MSMV_OWN_STAGE_F4
+#define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave: 8 waves' areas + queues = 40 KiB, 3-4 workgroups per CU
+#endif
+#ifndef MSMV_OWN_OCC
+#define MSMV_OWN_OCC 4, 8
+#endif
 
 // grad_out of point pt for channels c0 = 2*l32 and c0 + 1.  grad_out is [B,Q,C,P]: for P in
 // {1,2,4} the 2*P floats are contiguous and fetched with 8/16-byte loads (a half-wave reads
@@ -385,19 +396,32 @@ struct OwnHit {
 // layer after another accumulating into one buffer); a patch that no point reaches is then
 // left alone.
 template <int PT, bool ACC>
-__global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(MSMV_OWN_OCC)))
 msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 {
     constexpr int GP = PT == 4 ? 1 : OWN_GROUP;      // P = 4 fetches 32 B per lane and record
-    static_assert(OWN_QCAP % (2 * GP) == 0 && OWN_QCAP <= 64, "queue is consumed in whole groups");
+    static_assert(OWN_QCAP % (4 * GP) == 0 && OWN_QCAP <= 64, "queue rounds are consumed in whole groups");
+    // STAGED (P in {1,2,4} and row mode): the gradient rows of a whole queue of hits are copied
+    // global -> LDS by direct loads (no VGPR destination), all in flight at once, and read from
+    // there when the hits are applied.  P-strided rows (other P) are gathered into registers.
+    constexpr bool STAGED = MSMV_OWN_STAGED && PT != 0;
+    constexpr int ROW_F4 = PT == 4 ? 64 : PT == 2 ? 32 : 16;   // float4 per staged gradient row
+    constexpr int STAGE_F4 = MSMV_OWN_STAGE_F4;                // staging area per wave, in float4
+    constexpr int QC = STAGED && OWN_QCAP * ROW_F4 > STAGE_F4 ? STAGE_F4 / ROW_F4 : OWN_QCAP;   // records per queue round
+    static_assert(QC * ROW_F4 <= STAGE_F4, "a queue round's rows fit the wave's staging area");
     __shared__ float4 queue_all[OWN_WAVES][OWN_QCAP * 2];      // 2 float4 per record
-    __shared__ float red[OWN_WAVES / 2][32 * 64];              // partial tiles on their way to another wave
+    // staging areas; after the hit loop the same memory carries partial tiles between waves
+    __shared__ float4 stage_all[OWN_WAVES][STAGE_F4];
+    static_assert(sizeof(stage_all) >= (OWN_WAVES / 2) * 32 * 64 * sizeof(float), "partial tiles fit");
+    static_assert(QC >= 2 && QC % 2 == 0, "records are consumed in pairs");
+    float (*red)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(&stage_all[0][0]);
 
     const int lane = threadIdx.x & 63;
     const int l32 = lane & 31;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *queue = queue_all[wave];
+    [[maybe_unused]] float4 *stage = stage_all[wave];
 
     // ---- which patch: logical order [b][level, coarse first][view][tile][wave / K]
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
@@ -521,20 +545,80 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 any_hit = any_hit || nh > 0;
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
-            for (int qbase = 0; qbase < nh; qbase += OWN_QCAP) {
+            for (int qbase = 0; qbase < nh; qbase += QC) {
                 // every slot first gets a null record (a valid point, all weights 0), then
-                // hit lanes qbase .. qbase+QCAP-1 (in lane order) overwrite theirs: the queue
+                // hit lanes qbase .. qbase+QC-1 (in lane order) overwrite theirs: the queue
                 // can then be consumed in whole groups without branches around the loads
-                if (lane < OWN_QCAP) {
+                if (lane < QC) {
                     queue[lane * 2] = make_float4(__int_as_float(h.pt), 0.f, 0.f, 0.f);
                     queue[lane * 2 + 1] = make_float4(0.f, __uint_as_float(0xFFFFFFFFu), 0.f, 0.f);
                 }
                 const unsigned slot = (unsigned)(rank - qbase);
-                if (h.hit && slot < (unsigned)OWN_QCAP) {
+                if (h.hit && slot < (unsigned)QC) {
                     queue[slot * 2] = make_float4(__int_as_float(h.pt), h.cw1, h.cw2, h.cw3);
                     queue[slot * 2 + 1] = make_float4(h.cw4, __uint_as_float(h.pix), 0.f, 0.f);
                 }
-                const int cnt = min(OWN_QCAP, nh - qbase);
+                const int cnt = min(QC, nh - qbase);
+
+#ifdef MSMV_ABL_NORMW
+#define MSMV_OWN_MFMA(WA, GU) asm volatile("" ::"v"(WA), "v"(GU.x), "v"(GU.y));
+#else
+#define MSMV_OWN_MFMA(WA, GU)                                                                 \
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, GU.x, acc0, 0, 0, 0);     \
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, GU.y, acc1, 0, 0, 0);
+#endif
+                /* column of W for this half's record: the weight whose corner is pixel l32 */
+#define MSMV_OWN_WCOL(WA, RK, RO)                                                             \
+                    const unsigned pix = __float_as_uint(RO.y);                               \
+                    float WA = (pix >> 24) == (unsigned)l32 ? RO.x : 0.f;                     \
+                    WA = ((pix >> 16) & 255u) == (unsigned)l32 ? RK.w : WA;                   \
+                    WA = ((pix >> 8) & 255u) == (unsigned)l32 ? RK.z : WA;                    \
+                    WA = (pix & 255u) == (unsigned)l32 ? RK.y : WA;
+
+                if constexpr (STAGED) {
+                    // ---- all rows of the round: global -> LDS, 1 KiB per wave instruction
+                    constexpr int RPI = 64 / ROW_F4;                   // records per instruction
+                    constexpr int MAXI = QC / RPI;
+                    const int ninstr = (cnt + RPI - 1) / RPI;
+                    const float *qf = reinterpret_cast<const float *>(queue);
+                    int rpt[MAXI];
+#pragma unroll
+                    for (int i = 0; i < MAXI; ++i)                     // the record this lane copies a piece of
+                        rpt[i] = __float_as_int(qf[(i * RPI + lane / ROW_F4) * 8]);
+#pragma unroll
+                    for (int i = 0; i < MAXI; ++i) {
+                        if (i < ninstr) {                              // wave-uniform
+                            const int row = PT == 4 ? rpt[i] >> 2 : PT == 2 ? rpt[i] >> 1 : rpt[i];
+                            const float *src = a.gout + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
+                            __builtin_amdgcn_global_load_lds((msmv_gptr_t)src, (msmv_lptr_t)(stage + i * 64), 16, 0, 0);
+                        }
+                    }
+                    // ---- apply: half-wave `half` takes record 2*pair + half; the next pair's
+                    // record is fetched from the queue while this pair's product runs
+                    const int npairs = (cnt + 1) >> 1;
+                    float4 rk = queue[half * 2], ro = queue[half * 2 + 1];
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int u = 0; u < npairs; ++u) {
+                        const int r = u * 2 + half;
+                        const float *sp = reinterpret_cast<const float *>(stage + r * ROW_F4);
+                        float2 gu;
+                        if constexpr (PT == 1) {
+                            gu = *reinterpret_cast<const float2 *>(sp + l32 * 2);
+                        } else {
+                            const int p = __float_as_int(rk.x) & (PT - 1);
+                            gu.x = sp[l32 * 2 * PT + p];
+                            gu.y = sp[l32 * 2 * PT + PT + p];
+                        }
+                        const int rn = min(r + 2, QC - 2 + half);      // (the queue's last pair, at worst a null record)
+                        const float4 rk_n = queue[rn * 2], ro_n = queue[rn * 2 + 1];
+                        MSMV_OWN_WCOL(wa, rk, ro)
+                        MSMV_OWN_MFMA(wa, gu)
+                        rk = rk_n;
+                        ro = ro_n;
+                    }
+                    // the next round's copies must not overtake this round's LDS reads
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
                 const int ngroups = (cnt + 2 * GP - 1) / (2 * GP);
 
                 // Half-wave `half` takes record 2*pair + half.  Two register sets (A, B) hold
@@ -555,21 +639,9 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                     const float4 rk = queue[(((G) * GP + u) * 2 + half) * 2];                \
                     const float4 ro = queue[(((G) * GP + u) * 2 + half) * 2 + 1];            \
                     const float2 gu = msmv_select_grad<PT>(X##_g[u], X##_pt[u]);             \
-                    const unsigned pix = __float_as_uint(ro.y);                               \
-                    /* column of W for this half's record: the weight whose corner is pixel l32 */ \
-                    float wa = (pix >> 24) == (unsigned)l32 ? ro.x : 0.f;                     \
-                    wa = ((pix >> 16) & 255u) == (unsigned)l32 ? rk.w : wa;                   \
-                    wa = ((pix >> 8) & 255u) == (unsigned)l32 ? rk.z : wa;                    \
-                    wa = (pix & 255u) == (unsigned)l32 ? rk.y : wa;                           \
+                    MSMV_OWN_WCOL(wa, rk, ro)                                                 \
                     MSMV_OWN_MFMA(wa, gu)                                                     \
                 }
-#ifdef MSMV_ABL_NORMW
-#define MSMV_OWN_MFMA(WA, GU) asm volatile("" ::"v"(WA), "v"(GU.x), "v"(GU.y));
-#else
-#define MSMV_OWN_MFMA(WA, GU)                                                                 \
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, GU.x, acc0, 0, 0, 0);     \
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, GU.y, acc1, 0, 0, 0);
-#endif
                 MSMV_OWN_LOAD(a, 0)
                 for (int g = 0;;) {
                     if (g + 1 < ngroups) {
@@ -591,6 +663,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 }
 #undef MSMV_OWN_LOAD
 #undef MSMV_OWN_APPLY
+                }
+#undef MSMV_OWN_WCOL
 #undef MSMV_OWN_MFMA
             }
         }
@@ -598,6 +672,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 
     // ---- K > 1: sum the K partial tiles of a patch, halving the live waves per round.  The
     // round count is the workgroup's (one level, one K): every wave reaches every barrier.
+    if (K > 1)
+        __syncthreads();                 // every wave is done with its staging area: it is reused below
     for (int stride = K >> 1; stride >= 1; stride >>= 1) {
         const int slot = (wave >> klog) * (K >> 1) + (sub & (stride - 1));   // < OWN_WAVES / 2, one per pair
         if (sub >= stride && sub < 2 * stride) {
@@ -638,23 +714,29 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     if constexpr (ACC) {
         if (!any_hit)
             return;                                          // wave-uniform
-        // all 16 loads first (clamped to the patch's first pixel where the patch is ragged, so
-        // that no branch separates them), then the adds and stores
-        float2 old[16];
+        // in two batches of 8 pixels: all loads of a batch first (clamped to the patch's first
+        // pixel where the patch is ragged, so that no branch separates them), then the adds
+        // and stores; two batches keep the kernel's register count that of its main loop
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int pr = i / PATCH_W, pc = i % PATCH_W;
-            const bool in = pr < nrow && pc < ncol;
-            old[r] = *reinterpret_cast<const float2 *>(dst + (in ? ((size_t)pr * W + pc) * 64 : 0));
-        }
+        for (int r0b = 0; r0b < 16; r0b += 8) {
+            float2 old[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int pr = i / PATCH_W, pc = i % PATCH_W;
-            if (pr < nrow && pc < ncol)
-                *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) =
-                    make_float2(old[r].x + acc0[r], old[r].y + acc1[r]);
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0b + k;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int pr = i / PATCH_W, pc = i % PATCH_W;
+                const bool in = pr < nrow && pc < ncol;
+                old[k] = *reinterpret_cast<const float2 *>(dst + (in ? ((size_t)pr * W + pc) * 64 : 0));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0b + k;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int pr = i / PATCH_W, pc = i % PATCH_W;
+                if (pr < nrow && pc < ncol)
+                    *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) =
+                        make_float2(old[k].x + acc0[r], old[k].y + acc1[r]);
+            }
         }
     } else {
 #pragma unroll
