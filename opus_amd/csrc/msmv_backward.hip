@@ -450,6 +450,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 
     msmv_f32x16 acc0 = {}, acc1 = {};                        // even / odd channels
     [[maybe_unused]] bool any_hit = false;
+    [[maybe_unused]] bool touched = false;                   // ACC: pixel l32 of this half's records got a weight
 
     // ---- the bins that can reach this patch: one segment of the sorted entries per y-band
     // (all of them adjacent, i.e. one segment, when every x-band is wanted)
@@ -613,6 +614,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                         const float4 rk_n = queue[rn * 2], ro_n = queue[rn * 2 + 1];
                         MSMV_OWN_WCOL(wa, rk, ro)
                         MSMV_OWN_MFMA(wa, gu)
+                        if constexpr (ACC)
+                            touched = touched || wa != 0.f;
                         rk = rk_n;
                         ro = ro_n;
                     }
@@ -641,6 +644,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                     const float2 gu = msmv_select_grad<PT>(X##_g[u], X##_pt[u]);             \
                     MSMV_OWN_WCOL(wa, rk, ro)                                                 \
                     MSMV_OWN_MFMA(wa, gu)                                                     \
+                    if constexpr (ACC)                                                        \
+                        touched = touched || wa != 0.f;                                       \
                 }
                 MSMV_OWN_LOAD(a, 0)
                 for (int g = 0;;) {
@@ -714,8 +719,14 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     if constexpr (ACC) {
         if (!any_hit)
             return;                                          // wave-uniform
+        // Only the pixels that received a weight are read, added to and written back: on the
+        // finest level a layer's points reach about half of them.  Bit i of `pixels`: patch
+        // pixel i (either half-wave may have applied it).  Patches shared by several waves are
+        // on crowded levels, where every pixel is reached: all in-range pixels there.
+        const unsigned long long tb = __ballot(touched);
+        const unsigned pixels = K > 1 ? 0xFFFFFFFFu : (unsigned)tb | (unsigned)(tb >> 32);
         // in two batches of 8 pixels: all loads of a batch first (clamped to the patch's first
-        // pixel where the patch is ragged, so that no branch separates them), then the adds
+        // pixel where nothing is to be done, so that no branch separates them), then the adds
         // and stores; two batches keep the kernel's register count that of its main loop
 #pragma unroll
         for (int r0b = 0; r0b < 16; r0b += 8) {
@@ -725,7 +736,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 const int r = r0b + k;
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int pr = i / PATCH_W, pc = i % PATCH_W;
-                const bool in = pr < nrow && pc < ncol;
+                const bool in = pr < nrow && pc < ncol && ((pixels >> i) & 1u);
                 old[k] = *reinterpret_cast<const float2 *>(dst + (in ? ((size_t)pr * W + pc) * 64 : 0));
             }
 #pragma unroll
@@ -733,7 +744,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 const int r = r0b + k;
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int pr = i / PATCH_W, pc = i % PATCH_W;
-                if (pr < nrow && pc < ncol)
+                if (pr < nrow && pc < ncol && ((pixels >> i) & 1u))
                     *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) =
                         make_float2(old[k].x + acc0[r], old[k].y + acc1[r]);
             }
