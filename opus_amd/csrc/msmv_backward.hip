@@ -763,9 +763,12 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 // ======================================================================================
 // owner algorithm: d loc / d w gather (row of 16 lanes per point, like the forward)
 // ======================================================================================
-constexpr int GAT_THREADS = 256;
+#ifndef MSMV_GAT_THREADS
+#define MSMV_GAT_THREADS 256
+#endif
+constexpr int GAT_THREADS = MSMV_GAT_THREADS;
 #ifndef MSMV_GAT_GPW
-#define MSMV_GAT_GPW 2
+#define MSMV_GAT_GPW 1
 #endif
 constexpr int GAT_GROUPS_PER_WAVE = MSMV_GAT_GPW;
 
