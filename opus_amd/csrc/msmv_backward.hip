@@ -319,6 +319,9 @@ struct OwnerGeom {
 typedef float msmv_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(1))) const void *msmv_gptr_t;
 typedef __attribute__((address_space(3))) void *msmv_lptr_t;
+#ifndef MSMV_OWN_NT_STORE
+#define MSMV_OWN_NT_STORE 1
+#endif
 #ifndef MSMV_OWN_STAGED
 #define MSMV_OWN_STAGED 1
 #endif
@@ -385,6 +388,19 @@ __device__ __forceinline__ float2 msmv_select_grad(const GradRaw<PT> &r, int pt)
 }
 
 // What one lane knows about the bin entry it scanned (one point against this wave's run).
+// d feat is written once and not read again by this pass: a streaming (non-temporal) store
+// keeps it from displacing the feature maps and gradients that the following kernels read.
+__device__ __forceinline__ void msmv_store_stream(float *p, float x, float y)
+{
+#if MSMV_OWN_NT_STORE
+    typedef float msmv_f32x2 __attribute__((ext_vector_type(2)));
+    msmv_f32x2 v = {x, y};
+    __builtin_nontemporal_store(v, reinterpret_cast<msmv_f32x2 *>(p));
+#else
+    *reinterpret_cast<float2 *>(p) = make_float2(x, y);
+#endif
+}
+
 struct OwnHit {
     int pt;
     bool hit;                        // at least one corner lies in the patch
@@ -745,8 +761,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int pr = i / PATCH_W, pc = i % PATCH_W;
                 if (pr < nrow && pc < ncol && ((pixels >> i) & 1u))
-                    *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) =
-                        make_float2(old[k].x + acc0[r], old[k].y + acc1[r]);
+                    msmv_store_stream(dst + ((size_t)pr * W + pc) * 64, old[k].x + acc0[r], old[k].y + acc1[r]);
             }
         }
     } else {
@@ -755,7 +770,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
             const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int pr = i / PATCH_W, pc = i % PATCH_W;
             if (pr < nrow && pc < ncol)
-                *reinterpret_cast<float2 *>(dst + ((size_t)pr * W + pc) * 64) = make_float2(acc0[r], acc1[r]);
+                msmv_store_stream(dst + ((size_t)pr * W + pc) * 64, acc0[r], acc1[r]);
         }
     }
 }

@@ -16,6 +16,20 @@ constexpr int RL_TILE = 64;
 constexpr int RL_THREADS = 256;
 constexpr int RL_STRIDE = RL_TILE + 1;       // odd row stride: conflict-free column access
 
+// Every byte is read once and written once: streaming (non-temporal) accesses keep the copy
+// from displacing what the neighbouring kernels hold in L2 / Infinity Cache.
+typedef float rl_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rl_load_stream(const float *p)
+{
+    const rl_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const rl_f32x4 *>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void rl_store_stream(float *p, const float (&v)[4])
+{
+    const rl_f32x4 x = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(x, reinterpret_cast<rl_f32x4 *>(p));
+}
+
 struct RelayoutDims {
     int B, T, N, G, C, S;                     // S = H*W
     int s_tiles, c_tiles;
@@ -58,7 +72,7 @@ msmv_relayout_kernel(const float *__restrict__ src, float *__restrict__ dst, Rel
                 const float *p = chw_src + (size_t)c * d.S + q * 4;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (VEC && q * 4 + 3 < ns) {
-                    const float4 x = *reinterpret_cast<const float4 *>(p);
+                    const float4 x = rl_load_stream(p);
                     v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
                 } else {
 #pragma unroll
@@ -83,7 +97,7 @@ msmv_relayout_kernel(const float *__restrict__ src, float *__restrict__ dst, Rel
                     v[j] = tile[(q * 4 + j) * RL_STRIDE + s];
                 float *p = hwc_dst + (size_t)s * d.C + q * 4;
                 if (VEC && q * 4 + 3 < nc) {
-                    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                    rl_store_stream(p, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -101,7 +115,7 @@ msmv_relayout_kernel(const float *__restrict__ src, float *__restrict__ dst, Rel
                 const float *p = hwc_src + (size_t)s * d.C + q * 4;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (VEC && q * 4 + 3 < nc) {
-                    const float4 x = *reinterpret_cast<const float4 *>(p);
+                    const float4 x = rl_load_stream(p);
                     v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
                 } else {
 #pragma unroll
@@ -126,7 +140,7 @@ msmv_relayout_kernel(const float *__restrict__ src, float *__restrict__ dst, Rel
                     v[j] = tile[c * RL_STRIDE + q * 4 + j];
                 float *p = chw_dst + (size_t)c * d.S + q * 4;
                 if (VEC && q * 4 + 3 < ns) {
-                    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                    rl_store_stream(p, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
