@@ -26,6 +26,18 @@
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+#ifndef MSMV_GAT_STREAM_L0
+#define MSMV_GAT_STREAM_L0 1
+#endif
+typedef float bwd_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_level(const float *p, bool stream)   // (constant after unrolling)
+{
+    if (stream && MSMV_GAT_STREAM_L0) {
+        const bwd_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const bwd_f32x4 *>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return ld4(p);
+}
 
 // ======================================================================================
 // atomic algorithm
@@ -860,10 +872,11 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
             const int H = a.lvl[l].H, W = a.lvl[l].W;
             tap[l] = msmv_make_tap(lx, ly, H, W, view_ok);
             const float *base = a.lvl[l].feat + (slab * (size_t)(H * W)) * 64 + l16 * 4;
-            v[l][0] = ld4(base + (size_t)tap[l].o1 * 64);
-            v[l][1] = ld4(base + (size_t)tap[l].o2 * 64);
-            v[l][2] = ld4(base + (size_t)tap[l].o3 * 64);
-            v[l][3] = ld4(base + (size_t)tap[l].o4 * 64);
+            // (finest level: streaming hint, as in the forward)
+            v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l == 0);
+            v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l == 0);
+            v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l == 0);
+            v[l][3] = ld4_level(base + (size_t)tap[l].o4 * 64, l == 0);
         }
 
         // this row's 4 channels of grad_out for its point (inverse of the forward's store)

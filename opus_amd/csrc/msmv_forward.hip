@@ -19,12 +19,28 @@
 namespace {
 
 constexpr int FWD_THREADS = 256;          // 4 waves
+#ifndef MSMV_FWD_STREAM_L0
+#define MSMV_FWD_STREAM_L0 1
+#endif
 #ifndef MSMV_FWD_GPW
 #define MSMV_FWD_GPW 1
 #endif
 constexpr int FWD_GROUPS_PER_WAVE = MSMV_FWD_GPW;    // 4-point groups each wave walks through
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// The finest level is the largest (3/4 of the feature bytes) and the least re-used (a layer's
+// points touch under half of its pixels): its corners are fetched with a streaming hint so that
+// they do not displace the coarser levels, which every point re-reads, from L2.
+typedef float fwd_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_level(const float *p, bool stream)   // (constant after unrolling)
+{
+    if (stream && MSMV_FWD_STREAM_L0) {
+        const fwd_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fwd_f32x4 *>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        return ld4(p);
+    }
+}
 
 template <int NL, int PT>
 __global__ void __launch_bounds__(FWD_THREADS)
@@ -74,10 +90,10 @@ msmv_fwd_c64(const MsmvArgs a)
             const int H = a.lvl[l].H, W = a.lvl[l].W;
             tap[l] = msmv_make_tap(lx, ly, H, W, view_ok);
             const float *base = a.lvl[l].feat + (slab * (size_t)(H * W)) * 64 + l16 * 4;
-            v[l][0] = ld4(base + (size_t)tap[l].o1 * 64);
-            v[l][1] = ld4(base + (size_t)tap[l].o2 * 64);
-            v[l][2] = ld4(base + (size_t)tap[l].o3 * 64);
-            v[l][3] = ld4(base + (size_t)tap[l].o4 * 64);
+            v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l == 0);
+            v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l == 0);
+            v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l == 0);
+            v[l][3] = ld4_level(base + (size_t)tap[l].o4 * 64, l == 0);
         }
 
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
