@@ -26,6 +26,9 @@
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+#ifndef MSMV_STREAM_LEVELS
+#define MSMV_STREAM_LEVELS 1        // the finest levels whose corner loads carry the streaming hint
+#endif
 #ifndef MSMV_GAT_STREAM_L0
 #define MSMV_GAT_STREAM_L0 1
 #endif
@@ -873,10 +876,10 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
             tap[l] = msmv_make_tap(lx, ly, H, W, view_ok);
             const float *base = a.lvl[l].feat + (slab * (size_t)(H * W)) * 64 + l16 * 4;
             // (finest level: streaming hint, as in the forward)
-            v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l == 0);
-            v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l == 0);
-            v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l == 0);
-            v[l][3] = ld4_level(base + (size_t)tap[l].o4 * 64, l == 0);
+            v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l < MSMV_STREAM_LEVELS);
+            v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l < MSMV_STREAM_LEVELS);
+            v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l < MSMV_STREAM_LEVELS);
+            v[l][3] = ld4_level(base + (size_t)tap[l].o4 * 64, l < MSMV_STREAM_LEVELS);
         }
 
         // this row's 4 channels of grad_out for its point (inverse of the forward's store)

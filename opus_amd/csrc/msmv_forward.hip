@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int FWD_THREADS = 256;          // 4 waves
+#ifndef MSMV_STREAM_LEVELS
+#define MSMV_STREAM_LEVELS 1        // the finest levels whose corner loads carry the streaming hint
+#endif
 #ifndef MSMV_FWD_STREAM_L0
 #define MSMV_FWD_STREAM_L0 1
 #endif
@@ -90,10 +93,10 @@ msmv_fwd_c64(const MsmvArgs a)
             const int H = a.lvl[l].H, W = a.lvl[l].W;
             tap[l] = msmv_make_tap(lx, ly, H, W, view_ok);
             const float *base = a.lvl[l].feat + (slab * (size_t)(H * W)) * 64 + l16 * 4;
-            v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l == 0);
-            v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l == 0);
-            v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l == 0);
-            v[l][3] = ld4_level(base + (size_t)tap[l].o4 * 64, l == 0);
+            v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l < MSMV_STREAM_LEVELS);
+            v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l < MSMV_STREAM_LEVELS);
+            v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l < MSMV_STREAM_LEVELS);
+            v[l][3] = ld4_level(base + (size_t)tap[l].o4 * 64, l < MSMV_STREAM_LEVELS);
         }
 
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
