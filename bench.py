@@ -175,18 +175,26 @@ class Step:
         need = wrapper.backward_workspace_bytes(feats, loc, w, flags)
         self.ws = torch.empty(max(need, 16), dtype=torch.uint8, device=loc.device)
         self.events = []          # (kernel name, start, end)
+        self._boundary = None
 
     def _timed(self, name, fn, record):
+        """One event per launch boundary: the event that ends a launch also starts the next one
+        of the step (two records between launches doubled the idle time between kernels)."""
         if record:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            a = self._boundary
+            if a is None:
+                a = torch.cuda.Event(enable_timing=True)
+                a.record()
             fn()
+            b = torch.cuda.Event(enable_timing=True)
             b.record()
             self.events.append((name, a, b))
+            self._boundary = b
         else:
             fn()
 
     def run(self, record=True):
+        self._boundary = None
         for layer, (loc, w, g) in enumerate(self.sets):
             # layers of one decoder sample the same feature maps: the first backward writes
             # d feats, the others add to it (no zero-fill, no separate add pass)
