@@ -56,6 +56,9 @@ def parse_args():
                          "synthetic cameras x 8 ego poses (some points fall outside every image)")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU (B' = 32 * batch)")
     ap.add_argument("--bwd-algo", default="owner", choices=["owner", "atomic"])
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph and time its replays (no launch gaps); the "
+                         "per-kernel durations then come from evented steps run after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -345,12 +348,32 @@ def main():
     gc.disable()
     for _ in range(args.warmup):
         one_step(False)
+    graph = None
+    if args.graph:
+        assert not grad_buckets, "--graph does not cover the all-reduce workload"
+        # the library neither allocates nor synchronises: a step is capturable as it is
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step.run(False)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step.run(False)
+        graph.replay()
     odist.fence(dist, device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step(True)
+        if graph is not None:
+            graph.replay()
+        else:
+            one_step(True)
     odist.fence(dist, device)
     elapsed = odist.max_over_ranks(time.perf_counter() - t0, dist, device)
+    if graph is not None:
+        for _ in range(min(args.steps, 10)):
+            one_step(True)
+        torch.cuda.synchronize()
     gc.enable()
 
     if rank == 0:
@@ -394,6 +417,7 @@ def main():
                        "levels": LEVELS, "channels": CHANNELS,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
                        "points": args.points if not caller else "cameras",
+                       "launch": "HIP graph replay" if args.graph else "one call per kernel, HIP events between",
                        "frac_points_outside_image": outside,
                        "parallelism": f"dp{world} (batch-parallel, no data-path collective)"},
             "roofline": roofline,

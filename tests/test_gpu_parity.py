@@ -341,3 +341,44 @@ def test_full_size_forward_generic_vs_fast_and_subset_oracle(wr, oracle):
             assert_close(d[sl].cpu().numpy(), ref_df[i], GRAD_RTOL, f"dfeat{i} last slab [{algo}]")
         assert_close(dloc[sl].cpu().numpy(), ref_dloc, GRAD_RTOL, f"dloc last slab [{algo}]")
         assert_close(dw[sl].cpu().numpy(), ref_dw, GRAD_RTOL, f"dw last slab [{algo}]")
+
+
+def test_forward_backward_replay_from_a_hip_graph(wr, oracle):
+    """The library allocates nothing and never synchronises, so a forward + backward issued
+    with caller-owned buffers can be captured into a HIP graph once and replayed on new data."""
+    from opus_amd import _lib
+    feats, loc, w, grad_out = random_case(77, REAL_LEVELS, B=2, N=6, C=64, Q=64, P=2, oob_frac=0.2)
+    f = [dev(x) for x in feats]
+    l, ww, g = dev(loc), dev(w), dev(grad_out)
+    dfeats = [torch.empty_like(x) for x in f]
+    dloc, dw = torch.empty_like(l), torch.empty_like(ww)
+    ws = torch.empty(max(wr.backward_workspace_bytes(f, l, ww, _lib.BWD_OWNER), 16), dtype=torch.uint8, device="cuda")
+    out = torch.empty((2, 64, 64, 2), device="cuda")
+
+    def step():
+        out.copy_(wr.msmv_forward(f, l, ww))
+        wr.msmv_backward_into(g, f, l, ww, dfeats, dloc, dw, ws, flags=_lib.BWD_OWNER)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                   # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    # new inputs in the captured buffers, then replay
+    feats2, loc2, w2, grad2 = random_case(78, REAL_LEVELS, B=2, N=6, C=64, Q=64, P=2, oob_frac=0.2)
+    for dst, src in zip(f, feats2):
+        dst.copy_(dev(src))
+    l.copy_(dev(loc2)); ww.copy_(dev(w2)); g.copy_(dev(grad2))
+    for t in dfeats + [dloc, dw, out]:
+        t.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_close(out.cpu().numpy(), oracle.forward(feats2, loc2, w2), FWD_RTOL, "replayed forward")
+    ref_df, ref_dloc, ref_dw = oracle.backward(grad2, feats2, loc2, w2)
+    for i, d in enumerate(dfeats):
+        assert_close(d.cpu().numpy(), ref_df[i], GRAD_RTOL, f"replayed dfeat{i}")
+    assert_close(dloc.cpu().numpy(), ref_dloc, GRAD_RTOL, "replayed dloc")
+    assert_close(dw.cpu().numpy(), ref_dw, GRAD_RTOL, "replayed dw")
