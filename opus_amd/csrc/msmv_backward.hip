@@ -779,6 +779,14 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                     msmv_store_stream(dst + ((size_t)pr * W + pc) * 64, old[k].x + acc0[r], old[k].y + acc1[r]);
             }
         }
+    } else if (nrow == PATCH_H && ncol == PATCH_W) {
+        // a whole patch (all but the last row / column of patches): no per-pixel tests
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int pr = i / PATCH_W, pc = i % PATCH_W;
+            msmv_store_stream(dst + ((size_t)pr * W + pc) * 64, acc0[r], acc1[r]);
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -382,3 +382,29 @@ def test_forward_backward_replay_from_a_hip_graph(wr, oracle):
         assert_close(d.cpu().numpy(), ref_df[i], GRAD_RTOL, f"replayed dfeat{i}")
     assert_close(dloc.cpu().numpy(), ref_dloc, GRAD_RTOL, "replayed dloc")
     assert_close(dw.cpu().numpy(), ref_dw, GRAD_RTOL, "replayed dw")
+
+
+def test_offsets_beyond_32_bits(wr, oracle):
+    """520 batch slabs of the real level sizes: feature offsets pass 2^31 elements from slab 496
+    on (where the reference's int arithmetic wraps, msmv_sampling_forward.cu:127).  The last
+    slabs are checked against the oracle, forward and backward, both algorithms."""
+    B, N, C, Q, P = 520, 6, 64, 8, 2
+    gen = torch.Generator(device="cuda").manual_seed(520)
+    f = [torch.randn((B, N, h, w_, C), generator=gen, device="cuda") for h, w_ in REAL_LEVELS]
+    assert f[0].numel() > 2 ** 31
+    _, loc, w, grad_out = random_case(521, TINY_LEVELS, B, N, 1, Q, P, oob_frac=0.2)
+    grad_out = np.random.default_rng(3).standard_normal((B, Q, C, P)).astype(np.float32)
+    l, ww, g = dev(loc), dev(w), dev(grad_out)
+    out = wr.msmv_forward(f, l, ww)
+    tail = slice(B - 3, B)
+    feats_tail = [x[tail].cpu().numpy() for x in f]
+    ref_out = oracle.forward(feats_tail, loc[tail], w[tail])
+    assert_close(out[tail].cpu().numpy(), ref_out, FWD_RTOL, "forward, slabs past 2^31")
+    ref_df, ref_dloc, ref_dw = oracle.backward(grad_out[tail], feats_tail, loc[tail], w[tail])
+    for algo in ALGOS:
+        dfeats, dloc, dw = wr.msmv_backward(g, f, l, ww, algo=algo)
+        for i, d in enumerate(dfeats):
+            assert_close(d[tail].cpu().numpy(), ref_df[i], GRAD_RTOL, f"{algo} dfeat{i}, slabs past 2^31")
+        assert_close(dloc[tail].cpu().numpy(), ref_dloc, GRAD_RTOL, f"{algo} dloc")
+        assert_close(dw[tail].cpu().numpy(), ref_dw, GRAD_RTOL, f"{algo} dw")
+        del dfeats
