@@ -23,5 +23,8 @@ run L_cameras --points cameras --no-cpu-baseline
 run decoder-L --workload decoder-L --steps 20 --no-cpu-baseline
 run sampling4d-L --workload sampling4d-L --no-cpu-baseline
 run sampling4d-T --workload sampling4d-T --no-cpu-baseline
+run L_graph --graph --no-cpu-baseline
+run decoder-L_graph --workload decoder-L --graph --steps 20 --no-cpu-baseline
+run decoder-L_cameras --workload decoder-L --points cameras --steps 20 --no-cpu-baseline
 timeout -k 10 200 python3 tools/bench_sampling4d.py > "$O/${TAG}_sampling4d_fusion.json" 2> "$O/fusion.err" || exit 1
 echo "bench lines under $O"
