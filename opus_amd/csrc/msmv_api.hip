@@ -11,21 +11,6 @@ namespace {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-MsmvDiv make_div(int d)
-{
-    MsmvDiv r = {0, 0};
-    if (d >= 2) {
-        int l2 = 0;
-        while ((1ll << l2) < d)
-            ++l2;                                                // ceil(log2(d)), >= 1
-        const unsigned __int128 one = 1;
-        const unsigned __int128 num = one << (31 + l2);
-        r.magic = (uint32_t)((num + (unsigned)d - 1) / (unsigned)d);
-        r.shift = (uint32_t)(l2 - 1);
-    }
-    return r;
-}
-
 // Row mode (out / grad_out in [Bs, Q, G, T*P, C]): B must be Bs*T*G.
 int fill_rows(MsmvArgs &a, int T, int G)
 {
@@ -34,11 +19,11 @@ int fill_rows(MsmvArgs &a, int T, int G)
     a.rows = 1;
     a.T = T;
     a.G = G;
-    a.div_p = make_div(a.P);
-    a.div_q = make_div(a.Q);
-    a.div_t = make_div(T);
-    a.div_g = make_div(G);
-    a.div_tg = make_div(T * G);
+    a.div_p = msmv_make_div(a.P);
+    a.div_q = msmv_make_div(a.Q);
+    a.div_t = msmv_make_div(T);
+    a.div_g = msmv_make_div(G);
+    a.div_tg = msmv_make_div(T * G);
     return OPUS_MSMV_OK;
 }
 
@@ -68,7 +53,7 @@ int fill_common(MsmvArgs &a, int L, const int *hw, int B, int C, int N, int Q, i
     a.L = L; a.B = B; a.C = C; a.N = N; a.Q = Q; a.P = P;
     a.npts = (int)npts;
     a.qp = Q * P;
-    const MsmvDiv dqp = make_div(a.qp);
+    const MsmvDiv dqp = msmv_make_div(a.qp);
     a.qp_magic = dqp.magic;
     a.qp_shift = dqp.shift;
     return OPUS_MSMV_OK;

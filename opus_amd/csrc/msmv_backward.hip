@@ -166,18 +166,29 @@ __device__ __forceinline__ int msmv_band_of(float y)
 
 // Conservative band interval of the locations whose 2x2 footprint can reach pixels
 // lo..hi (inclusive) of an axis with `size` pixels: floor(v*(size-1)) is lo-1..hi, i.e.
-// v*(size-1) in [lo-1, hi+1).  The 1e-3 margin (in bands) dwarfs the rounding of either
-// product.  size == 1 maps every location to pixel 0.
+// v*(size-1) in [lo-1, hi+1), so the band floor(v*NB) lies between floor(NB*(lo-1)/(size-1))
+// and floor(NB*(hi+1)/(size-1)).  Integer arithmetic only (the caller is wave-uniform: this
+// runs on the scalar unit; `sm1` divides by size-1).  The rounding of the two float products
+// (location -> pixel, location -> band) is below 1e-6 bands, which only matters when a bound is
+// an exact integer (the lower one then steps down a band) - or on axes of thousands of pixels,
+// where the interval is simply widened by a band on each side.  size == 1 maps every location
+// to pixel 0.
 template <int NB>
-__device__ __forceinline__ void msmv_band_range(int lo, int hi, int size, int &b_lo, int &b_hi)
+__device__ __forceinline__ void msmv_band_range(int lo, int hi, int size, MsmvDiv sm1, int &b_lo, int &b_hi)
 {
     b_lo = 0;
     b_hi = NB - 1;
     if (size > 1) {
-        const float flo = (float)NB * (float)(lo - 1) / (float)(size - 1) - 1e-3f;
-        const float fhi = (float)NB * (float)(hi + 1) / (float)(size - 1) + 1e-3f;
-        b_lo = flo <= 0.f ? 0 : min((int)flo, NB - 1);
-        b_hi = fhi >= (float)(NB - 1) ? NB - 1 : max((int)fhi, 0);
+        const int den = size - 1;
+        const int wide = den >= 4096 ? 1 : 0;
+        const int tl = NB * (lo - 1);
+        if (tl > 0) {
+            const int q = (int)msmv_div((uint32_t)tl, sm1);
+            const int lower = (tl - q * den == 0 || wide) ? q - 1 : q;
+            b_lo = min(max(lower, 0), NB - 1);
+        }
+        const int qh = (int)msmv_div((uint32_t)(NB * (hi + 1)), sm1) + wide;
+        b_hi = min(qh, NB - 1);
     }
 }
 
@@ -328,6 +339,11 @@ struct OwnerGeom {
     int patch_cols[MSMV_MAX_LEVELS];        // patches per row of patches: ceil(W / PATCH_W)
     int patches[MSMV_MAX_LEVELS];           // patches per slab: ceil(H / PATCH_H) * patch_cols
     int split_log2[MSMV_MAX_LEVELS];        // log2 K: waves per patch at the level (K in {1,2,4,8})
+    MsmvDiv div_tiles[MSMV_MAX_LEVELS];     // divisors for the kernel's index arithmetic: tiles_per_level,
+    MsmvDiv div_cols[MSMV_MAX_LEVELS];      // patch_cols,
+    MsmvDiv div_hm1[MSMV_MAX_LEVELS];       // H - 1 and
+    MsmvDiv div_wm1[MSMV_MAX_LEVELS];       // W - 1 of the level,
+    MsmvDiv div_tiles_per_b;                // and tiles_per_b
     int tiles_per_b;                         // N * sum over levels
 };
 
@@ -456,7 +472,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
 
     // ---- which patch: logical order [b][level, coarse first][view][tile][wave / K]
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
-    const int b = id / geo.tiles_per_b;
+    const int b = (int)msmv_div((uint32_t)id, geo.div_tiles_per_b);
     id -= b * geo.tiles_per_b;
     int l = a.L - 1;
     for (; l > 0; --l) {
@@ -465,7 +481,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
             break;
         id -= n;
     }
-    const int view = id / geo.tiles_per_level[l];
+    const int view = (int)msmv_div((uint32_t)id, geo.div_tiles[l]);
     const int tile_idx = id - view * geo.tiles_per_level[l];
     const int klog = geo.split_log2[l];
     const int K = 1 << klog;                                 // waves sharing a patch
@@ -475,7 +491,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     const int patch = idle ? 0 : patch_raw;                  // the barriers below, stores nothing
     const int H = a.lvl[l].H, W = a.lvl[l].W;
     const int S = H * W;
-    const int prow = patch / geo.patch_cols[l];
+    const int prow = (int)msmv_div((uint32_t)patch, geo.div_cols[l]);
     const int r0 = prow * PATCH_H, c0 = (patch - prow * geo.patch_cols[l]) * PATCH_W;
     const int nrow = min(PATCH_H, H - r0), ncol = min(PATCH_W, W - c0);
 
@@ -486,8 +502,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     // ---- the bins that can reach this patch: one segment of the sorted entries per y-band
     // (all of them adjacent, i.e. one segment, when every x-band is wanted)
     int yb_lo, yb_hi, xb_lo, xb_hi;
-    msmv_band_range<BIN_YB>(r0, r0 + nrow - 1, H, yb_lo, yb_hi);
-    msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, xb_lo, xb_hi);
+    msmv_band_range<BIN_YB>(r0, r0 + nrow - 1, H, geo.div_hm1[l], yb_lo, yb_hi);
+    msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, geo.div_wm1[l], xb_lo, xb_hi);
     const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
     const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB
     const int *off = ws.offsets + (size_t)b * (ws.keys + 1) + view * BIN_PER_VIEW;
@@ -1083,9 +1099,14 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
             geo.split_log2[l] = klog;
             const int per_wg = OWN_WAVES >> klog;
             geo.tiles_per_level[l] = (geo.patches[l] + per_wg - 1) / per_wg;
+            geo.div_tiles[l] = msmv_make_div(geo.tiles_per_level[l]);
+            geo.div_cols[l] = msmv_make_div(geo.patch_cols[l]);
+            geo.div_hm1[l] = msmv_make_div(a.lvl[l].H - 1);
+            geo.div_wm1[l] = msmv_make_div(a.lvl[l].W - 1);
             per_view += geo.tiles_per_level[l];
         }
         geo.tiles_per_b = per_view * a.N;
+        geo.div_tiles_per_b = msmv_make_div(geo.tiles_per_b);
         const long long ntiles = (long long)geo.tiles_per_b * a.B;
         if (ntiles > 0x7FFFFFFFll)
             return hipErrorInvalidValue;

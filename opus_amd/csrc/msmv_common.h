@@ -42,6 +42,21 @@ struct MsmvArgs {
     MsmvDiv div_p, div_q, div_t, div_g, div_tg;
 };
 
+inline MsmvDiv msmv_make_div(int d)
+{
+    MsmvDiv r = {0, 0};
+    if (d >= 2) {
+        int l2 = 0;
+        while ((1ll << l2) < d)
+            ++l2;                                                // ceil(log2(d)), >= 1
+        const unsigned __int128 one = 1;
+        const unsigned __int128 num = one << (31 + l2);
+        r.magic = (uint32_t)((num + (unsigned)d - 1) / (unsigned)d);
+        r.shift = (uint32_t)(l2 - 1);
+    }
+    return r;
+}
+
 __device__ __forceinline__ uint32_t msmv_div(uint32_t x, MsmvDiv d)
 {
     return d.magic ? __umulhi(x, d.magic) >> d.shift : x;
