@@ -50,10 +50,13 @@ def parse_args():
                     help="{T,S,M,L}-fwd | {T,S,M,L}-fwdbwd | decoder-L (6 layers fwd+bwd) | "
                          "train-M (6 x (2 fwd + 1 bwd) + RCCL all-reduce of a 0.3 GB gradient) | "
                          "sampling4d-{T,S,M,L} (projection + op in the caller's layout, fwd+bwd)")
-    ap.add_argument("--points", default="uniform", choices=["uniform", "cameras"],
+    ap.add_argument("--points", default="uniform", choices=["uniform", "cameras", "queries"],
                     help="uniform: u,v ~ U(0,1), view ~ U{0..5} (every corner in range: the byte count is "
                          "exact); cameras: 3-D points in the occupancy range projected into a ring of 6 "
-                         "synthetic cameras x 8 ego poses (some points fall outside every image)")
+                         "synthetic cameras x 8 ego poses (some points fall outside every image); queries: as "
+                         "cameras, but the 3-D points come from the decoder's sampling module at its initial "
+                         "weights (each query's G*P points scattered around the query's own points, the same "
+                         "points in all 8 frames)")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU (B' = 32 * batch)")
     ap.add_argument("--bwd-algo", default="owner", choices=["owner", "atomic"])
     ap.add_argument("--graph", action="store_true",
@@ -79,7 +82,7 @@ def make_inputs(Bp, Q, P, seed, device, n_sets=1):
     return feats, sets
 
 
-def camera_sets(Bp, Q, P, seed, device, n_sets):
+def camera_sets(Bp, Q, P, seed, device, n_sets, from_queries=False):
     """Caller-side inputs of sampling_4d: 3-D points in pc_range = [-40,-40,-1, 40,40,5.4]
     (configs/opus-*: point_cloud_range), softmax scale weights, ring-of-cameras occ2img."""
     import numpy as np
@@ -93,8 +96,22 @@ def camera_sets(Bp, Q, P, seed, device, n_sets):
     occ2img = torch.from_numpy(synthetic_occ2img(np.random.default_rng(seed), B, T, N, 256, 704)).to(device)
     sets = []
     for _ in range(n_sets):
-        pts = torch.rand((B, Q, T, G, P, 3), generator=gen, device=device) * (hi - lo) + lo
-        sw = torch.softmax(torch.randn((B, Q, G, T, P, L), generator=gen, device=device), -1)
+        if from_queries:
+            # models/opus_transformer.py:321-327: zero offset weights, bias ~ U(-0.5, 0.5); a query
+            # holds 8 points within about a metre of its centre
+            E, R = 256, 8
+            qc = torch.rand((B, Q, 1, 3), generator=gen, device=device)
+            qp = (qc + 0.02 * torch.randn((B, Q, R, 3), generator=gen, device=device)).clamp(0, 1)
+            feat = torch.randn((B, Q, E), generator=gen, device=device)
+            ob = torch.rand((G * P * 3,), generator=gen, device=device) - 0.5
+            sw_w = 0.02 * torch.randn((G * P * L, E), generator=gen, device=device)
+            pts, sw = opus_sampling.sampling_inputs(
+                qp, feat, torch.zeros((G * P * 3, E), device=device), ob, sw_w,
+                torch.zeros((G * P * L,), device=device), T, G, P, L, [-40.0, -40.0, -1.0, 40.0, 40.0, 5.4])
+            pts, sw = pts.contiguous(), sw.contiguous()
+        else:
+            pts = torch.rand((B, Q, T, G, P, 3), generator=gen, device=device) * (hi - lo) + lo
+            sw = torch.softmax(torch.randn((B, Q, G, T, P, L), generator=gen, device=device), -1)
         sets.append((pts, sw, occ2img))
     return sets
 
@@ -314,8 +331,8 @@ def main():
     Bp = SLABS_PER_SAMPLE * args.batch
     feats, sets = make_inputs(Bp, Q, P, 1234 + rank, device, n_sets=n_layers)
     caller = None
-    if args.points == "cameras" or wl.startswith("sampling4d-"):
-        cam = camera_sets(Bp, Q, P, 1234 + rank, device, n_layers)
+    if args.points != "uniform" or wl.startswith("sampling4d-"):
+        cam = camera_sets(Bp, Q, P, 1234 + rank, device, n_layers, from_queries=args.points == "queries")
         for (loc, w, g), (pts, sw, occ2img) in zip(sets, cam):
             opus_sampling.project_pack_into(pts, sw, occ2img, 256, 704, N_VIEWS, loc, w)
         if wl.startswith("sampling4d-"):
@@ -416,7 +433,7 @@ def main():
                        "name": wl, "Q": Q, "P": P, "slabs_per_gpu": Bp, "views": N_VIEWS,
                        "levels": LEVELS, "channels": CHANNELS,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
-                       "points": args.points if not caller else "cameras",
+                       "points": args.points if (not caller or args.points != "uniform") else "cameras",
                        "launch": "HIP graph replay" if args.graph else "one call per kernel, HIP events between",
                        "frac_points_outside_image": outside,
                        "parallelism": f"dp{world} (batch-parallel, no data-path collective)"},

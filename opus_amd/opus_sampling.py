@@ -233,3 +233,31 @@ def sampling_4d(sample_points, mlvl_feats, scale_weights, occ2img, image_h, imag
     loc, w = project_and_pack_torch(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
     final = msmv_sampling(mlvl_feats, loc, w)
     return unpack(final, B, T, G)
+
+
+def sampling_inputs(query_points, query_feat, offset_weight, offset_bias, scale_weight, scale_bias,
+                    num_frames, num_groups, num_points, num_levels, pc_range):
+    """What the decoder's sampling module feeds ``sampling_4d`` (restates
+    models/opus_transformer.py:337-358 and models/bbox/utils.py:88-93; not pinned by a fixture:
+    the module itself needs mmcv to import).
+
+    query_points [B, Q, R, 3] in [0, 1] (R points per query), query_feat [B, Q, E];
+    offset_* / scale_* are the weights of the two Linear layers (E -> G*P*3 and E -> G*P*L).
+    Returns sample_points [B, Q, T, G, P, 3] (metres, the same points for every frame: an
+    expanded view) and scale_weights [B, Q, G, T, P, L] (softmax over levels, expanded over T).
+    """
+    B, Q = query_points.shape[:2]
+    T, G, P, L = num_frames, num_groups, num_points, num_levels
+    lo = query_points.new_tensor(pc_range[:3])
+    hi = query_points.new_tensor(pc_range[3:])
+    pts = query_points * (hi - lo) + lo                                        # decode_points
+    if pts.shape[2] == 1:
+        center, scale = pts, torch.zeros_like(pts)
+    else:
+        center = pts.mean(dim=2, keepdim=True)
+        scale = pts.std(dim=2, keepdim=True)
+    offset = torch.nn.functional.linear(query_feat, offset_weight, offset_bias).view(B, Q, -1, 3)
+    sp = (center + offset * scale).view(B, Q, 1, G, P, 3).expand(B, Q, T, G, P, 3)
+    sw = torch.nn.functional.linear(query_feat, scale_weight, scale_bias).view(B, Q, G, 1, P, L)
+    sw = torch.softmax(sw, dim=-1).expand(B, Q, G, T, P, L)
+    return sp, sw

@@ -144,3 +144,26 @@ def test_relayout_features_matches_decoder_convention():
     assert out.shape == (B * T * G, N, H, W, C) and out.is_contiguous()
     b, t, g, n, c, h, w = 1, 2, 1, 1, 3, 2, 4
     assert out[(b * T + t) * G + g, n, h, w, c] == feat[b, t * N + n, g * C + c, h, w]
+
+
+def test_sampling_inputs_follow_the_decoder_module():
+    """Restatement of models/opus_transformer.py:337-358: centre + offset * std, the same points in
+    every frame, softmax over levels; a query with a single point has scale 0."""
+    from opus_amd import opus_sampling
+    B, Q, R, E, T, G, P, L = 2, 5, 8, 16, 3, 2, 4, 4
+    gen = torch.Generator().manual_seed(0)
+    qp, feat = torch.rand((B, Q, R, 3), generator=gen), torch.randn((B, Q, E), generator=gen)
+    ow, ob = torch.randn((G * P * 3, E), generator=gen), torch.randn((G * P * 3,), generator=gen)
+    sw_w, sw_b = torch.randn((G * P * L, E), generator=gen), torch.randn((G * P * L,), generator=gen)
+    rng = [-40.0, -40.0, -1.0, 40.0, 40.0, 5.4]
+    sp, sw = opus_sampling.sampling_inputs(qp, feat, ow, ob, sw_w, sw_b, T, G, P, L, rng)
+    assert sp.shape == (B, Q, T, G, P, 3) and sw.shape == (B, Q, G, T, P, L)
+    assert torch.equal(sp[:, :, 0], sp[:, :, T - 1]) and torch.equal(sw[:, :, :, 0], sw[:, :, :, T - 1])
+    assert torch.allclose(sw.sum(-1), torch.ones(B, Q, G, T, P))
+    lo, hi = torch.tensor(rng[:3]), torch.tensor(rng[3:])
+    pts = qp * (hi - lo) + lo
+    off = (feat @ ow.T + ob).view(B, Q, G, P, 3)
+    want = pts.mean(2)[:, :, None, None] + off * pts.std(2)[:, :, None, None]
+    assert torch.allclose(sp[:, :, 0], want, atol=1e-5)
+    sp1, _ = opus_sampling.sampling_inputs(qp[:, :, :1], feat, ow, ob, sw_w, sw_b, T, G, P, L, rng)
+    assert torch.allclose(sp1[:, :, 0, 0, 0], pts[:, :, 0])
