@@ -11,7 +11,6 @@ Differences from the device kernels that tests must account for
     identical for locations of the form view/(N-1);
   * the gradient of the view coordinate is non-zero here and exactly 0 on the device.
 """
-import torch
 import torch.nn.functional as F
 
 
