@@ -432,6 +432,17 @@ __device__ __forceinline__ void msmv_store_stream(float *p, float x, float y)
 #endif
 }
 
+__device__ __forceinline__ float2 msmv_load_stream(const float *p)
+{
+#if MSMV_OWN_NT_STORE
+    typedef float msmv_f32x2 __attribute__((ext_vector_type(2)));
+    const msmv_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const msmv_f32x2 *>(p));
+    return make_float2(v[0], v[1]);
+#else
+    return *reinterpret_cast<const float2 *>(p);
+#endif
+}
+
 struct OwnHit {
     int pt;
     bool hit;                        // at least one corner lies in the patch
@@ -784,7 +795,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int pr = i / PATCH_W, pc = i % PATCH_W;
                 const bool in = pr < nrow && pc < ncol && ((pixels >> i) & 1u);
-                old[k] = *reinterpret_cast<const float2 *>(dst + (in ? ((size_t)pr * W + pc) * 64 : 0));
+                old[k] = msmv_load_stream(dst + (in ? ((size_t)pr * W + pc) * 64 : 0));
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
