@@ -321,12 +321,18 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 // flight, so its run time grows with the hits of its patch: a patch of a coarse level (or of a
 // crowded image region) collects hundreds of hits where a fine one collects a handful, and
 // those few long waves would finish last.  A level whose patches expect many hits is
-// therefore worked on by K = 2, 4 or 8 waves per patch: wave k of the K takes entries
+// therefore worked on by K = 2 or 4 waves per patch: wave k of the K takes entries
 // k, k + K, k + 2K, ... of the patch's bins, and the K partial accumulators are summed through
-// LDS (log2 K rounds) before the store.  A workgroup is always 8 waves = 8 / K patches.
+// LDS (log2 K rounds) before the store.  A workgroup is always OWN_WAVES waves = OWN_WAVES / K patches.
 constexpr int PATCH_H = 4, PATCH_W = 8;
 static_assert(PATCH_H * PATCH_W == 32, "a patch is the M = 32 dimension of the MFMA tile");
-constexpr int OWN_WAVES = 8;                     // waves per workgroup; at most all of them share one patch
+#ifndef MSMV_OWN_WAVES
+#define MSMV_OWN_WAVES 4
+#endif
+// waves per workgroup (a power of two); at most all of them share one patch.  With 72 VGPRs a SIMD
+// holds 7 waves: workgroups of 4 waves fill them (7 per CU), workgroups of 8 only 6 of 7
+// (measured 183 vs 198 us at OPUS-L; 2 waves: 175 us uniform but no better on crowded images)
+constexpr int OWN_WAVES = MSMV_OWN_WAVES;
 constexpr int OWN_THREADS = OWN_WAVES * 64;
 #ifndef MSMV_OWN_SPLIT_HITS
 #define MSMV_OWN_SPLIT_HITS 64                   // expected hits per wave above which a level's patches are shared
@@ -1105,7 +1111,7 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
             // a point touches ~1.4 patches of a level: expected hits per patch, uniform points
             const double expect = 1.4 * (double)a.qp / ((double)a.N * geo.patches[l]);
             int klog = 0;
-            while (klog < 3 && expect > (double)MSMV_OWN_SPLIT_HITS * (1 << klog))
+            while ((2 << klog) <= OWN_WAVES && expect > (double)MSMV_OWN_SPLIT_HITS * (1 << klog))
                 ++klog;
             geo.split_log2[l] = klog;
             const int per_wg = OWN_WAVES >> klog;
