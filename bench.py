@@ -62,6 +62,10 @@ def parse_args():
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph and time its replays (no launch gaps); the "
                          "per-kernel durations then come from evented steps run after the timed region")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="record the per-kernel HIP events in every n-th timed step only: an event record "
+                         "idles the GPU for several microseconds, five of them per step cost ~8 %% of an "
+                         "OPUS-L step (1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -229,7 +233,11 @@ class Step:
             if not self.do_bwd:
                 continue
             args = (g, self.feats, loc, w, self.dfeats, self.dloc, self.dw, self.ws)
-            if self.algo == "owner":
+            if self.algo == "owner" and not record:
+                # the product path: one call issues the sort, the d-feat and the gather kernels
+                wrapper.msmv_backward_into(*args, flags=_lib.BWD_OWNER | acc, rows=rows)
+            elif self.algo == "owner":
+                # the same launches stage by stage, so that each kernel gets its own event pair
                 for name, bit in (("msmv_bin_sort", _lib.BWD_STAGE_BIN),
                                   ("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT),
                                   ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
@@ -380,11 +388,11 @@ def main():
         graph.replay()
     odist.fence(dist, device)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         if graph is not None:
             graph.replay()
         else:
-            one_step(True)
+            one_step(i % args.event_every == 0)
     odist.fence(dist, device)
     elapsed = odist.max_over_ranks(time.perf_counter() - t0, dist, device)
     if graph is not None:
@@ -434,7 +442,8 @@ def main():
                        "levels": LEVELS, "channels": CHANNELS,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
                        "points": args.points if (not caller or args.points != "uniform") else "cameras",
-                       "launch": "HIP graph replay" if args.graph else "one call per kernel, HIP events between",
+                       "launch": "HIP graph replay" if args.graph else
+                                 f"one call per kernel; HIP events between them in every {args.event_every}. timed step",
                        "frac_points_outside_image": outside,
                        "parallelism": f"dp{world} (batch-parallel, no data-path collective)"},
             "roofline": roofline,
