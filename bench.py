@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="L-fwdbwd",
-                    help="{T,S,M,L}-fwd | {T,S,M,L}-fwdbwd | decoder-L (6 layers fwd+bwd) | "
+                    help="{T,S,M,L}-fwd | {T,S,M,L}-fwdbwd | decoder-{T,S,M,L} (6 layers fwd+bwd) | "
                          "train-M (6 x (2 fwd + 1 bwd) + RCCL all-reduce of a 0.3 GB gradient) | "
                          "sampling4d-{T,S,M,L} (projection + op in the caller's layout, fwd+bwd)")
     ap.add_argument("--points", default="uniform", choices=["uniform", "cameras", "queries"],
@@ -324,8 +324,9 @@ def main():
     # ---- workload
     wl = args.workload
     n_layers, n_fwd, allreduce_bytes = 1, 1, 0
-    if wl == "decoder-L":
-        variant, do_bwd, n_layers = "L", True, 6
+    if wl.startswith("decoder-"):
+        variant, do_bwd, n_layers = wl.split("-")[1], True, 6
+        assert variant in VARIANTS, wl
     elif wl == "train-M":
         variant, do_bwd, n_layers, n_fwd, allreduce_bytes = "M", True, 6, 2, 300 * 1000 * 1000
     elif wl.startswith("sampling4d-"):

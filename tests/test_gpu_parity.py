@@ -408,3 +408,37 @@ def test_offsets_beyond_32_bits(wr, oracle):
         assert_close(dloc[tail].cpu().numpy(), ref_dloc, GRAD_RTOL, f"{algo} dloc")
         assert_close(dw[tail].cpu().numpy(), ref_dw, GRAD_RTOL, f"{algo} dw")
         del dfeats
+
+
+def test_randomised_shapes_against_the_oracle(wr, oracle):
+    """Forty seeded random configurations (level count and sizes, views, queries, points per query,
+    out-of-range share; C = 64 so that both backward algorithms apply), every tensor against the
+    oracle; where the batch allows it, row mode against the same results re-ordered."""
+    from opus_amd import opus_sampling
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        L = int(rng.choice([4, 5]))
+        levels = [(int(rng.integers(1, 41)), int(rng.integers(1, 41))) for _ in range(L)]
+        B, N = int(rng.integers(1, 7)), int(rng.integers(1, 9))
+        Q, P = int(rng.integers(1, 301)), int(rng.choice([1, 2, 3, 4, 5, 8]))
+        feats, loc, w, grad_out = random_case(9000 + case, levels, B, N, 64, Q, P,
+                                              oob_frac=float(rng.choice([0.0, 0.3, 0.8])))
+        what = f"case {case}: levels {levels} B{B} N{N} Q{Q} P{P}"
+        try:
+            _check_all(wr, oracle, feats, loc, w, grad_out)
+        except AssertionError as e:
+            raise AssertionError(f"{what}: {e}") from e
+        # row mode with (T, G) = (B, 1) and (1, B): the op's results in the caller's layout
+        f = [dev(x) for x in feats]
+        l, ww, g = dev(loc), dev(w), dev(grad_out)
+        plain = wr.msmv_forward(f, l, ww)
+        for T, G in ((B, 1), (1, B)):
+            rows = wr.msmv_forward(f, l, ww, rows=(T, G))
+            assert torch.equal(rows, opus_sampling.unpack(plain, 1, T, G).contiguous()), what
+            g_rows = opus_sampling.unpack(g, 1, T, G).contiguous()
+            df_r, dl_r, dw_r = wr.msmv_backward(g_rows, f, l, ww, algo="owner", rows=(T, G))
+            df_p, dl_p, dw_p = wr.msmv_backward(g, f, l, ww, algo="owner")
+            for a_, b_ in zip(df_r, df_p):
+                assert_close(a_.cpu().numpy(), b_.cpu().numpy(), GRAD_RTOL, what + " row-mode dfeat")
+            assert_close(dl_r.cpu().numpy(), dl_p.cpu().numpy(), 1e-5, what + " row-mode dloc")
+            assert_close(dw_r.cpu().numpy(), dw_p.cpu().numpy(), 1e-5, what + " row-mode dw")
