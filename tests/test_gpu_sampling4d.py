@@ -342,3 +342,37 @@ def test_feature_grad_sink_through_relayout_and_sampling_4d(ops):
         assert_close(a.grad.cpu().numpy(), b.grad.cpu().numpy(), GRAD_RTOL, f"d raw feat {i}")
     assert_close(p_a.grad.cpu().numpy(), p_b.grad.cpu().numpy(), GRAD_RTOL, "d sample_points")
     assert_close(s_a.grad.cpu().numpy(), s_b.grad.cpu().numpy(), GRAD_RTOL, "d scale_weights")
+
+
+def test_project_pack_randomised_shapes(ops):
+    """Twenty seeded random caller shapes: packed locations / weights and both gradients against
+    the numpy oracle (same acceptance rule for near-threshold camera choices as above)."""
+    from oracle import sampling4d_oracle as so
+    rng = np.random.default_rng(77)
+    H, W = 256, 704
+    for case in range(20):
+        B, Q = int(rng.integers(1, 4)), int(rng.integers(1, 120))
+        T, G, P = int(rng.integers(1, 9)), int(rng.integers(1, 5)), int(rng.integers(1, 9))
+        N, L = int(rng.integers(2, 8)), int(rng.choice([1, 4, 5, 8]))
+        pts, sw, occ2img = sampling4d_case(500 + case, B, Q, T, G, P, N, L, H, W)
+        ref_loc, ref_w = so.project_pack(pts, sw, occ2img, H, W, N)
+        d_pts, d_sw = dev(pts).requires_grad_(True), dev(sw).requires_grad_(True)
+        loc, w = ops.project_and_pack(d_pts, d_sw, dev(occ2img), H, W, N)
+        what = f"case {case}: B{B} Q{Q} T{T} G{G} P{P} N{N} L{L}"
+        same = check_packed(loc.detach().cpu().numpy(), w.detach().cpu().numpy(), ref_loc, ref_w,
+                            pts, occ2img, H, W, N, what)
+        dloc = rng.standard_normal(ref_loc.shape).astype(np.float32)
+        dloc[~same] = 0
+        dw = rng.standard_normal(ref_w.shape).astype(np.float32)
+        torch.autograd.backward([loc, w], [dev(dloc), dev(dw)])
+        ref_dpts, ref_dsw = so.project_pack_backward(dloc, dw, pts, occ2img, ref_loc, H, W, N)
+        # A point a few centimetres from its camera's plane has a gradient ~ 1/z^2 in the millions
+        # and z itself is a float32 sum with cancellation: such elements are held to 5e-3 of
+        # their own value, everything else to 1e-5 of the tensor's largest ordinary element.
+        got = d_pts.grad.cpu().numpy().astype(np.float64)
+        err = np.abs(got - ref_dpts)
+        ordinary = np.abs(ref_dpts) < 1e3
+        scale = np.abs(ref_dpts[ordinary]).max() if ordinary.any() else 1.0
+        ok = (err <= 1e-5 * scale) | (err <= 5e-3 * np.abs(ref_dpts))
+        assert np.isfinite(got).all() and ok.all(), f"{what} d sample_points: max|diff| {err[~ok].max():.3e}"
+        assert np.array_equal(d_sw.grad.cpu().numpy(), ref_dsw), what
