@@ -153,10 +153,14 @@ int opus_msmv_backward_rows(int L, const float *grad_out, const float *const *fe
  *      weights [B*G*T,Q,P,L] = the scale weights re-packed.  Points are packed in (B,T,G)
  *      order and weights in (B,G,T) order, as the reference does (opus_sampling.py:104-112).
  * Requires N >= 2 (the reference divides by N-1, opus_sampling.py:101).
+ * flags: OPUS_MSMV_PACK_SHARED_FRAMES - the T frames share one set of points and weights, as the
+ * decoder produces them before it expands them over T (models/opus_transformer.py:350-358):
+ * sample_points is then [B,Q,G,P,3] and scale_weights [B,Q,G,P,L], outputs unchanged.
  */
+#define OPUS_MSMV_PACK_SHARED_FRAMES 0x1
 int opus_msmv_project_pack(const float *sample_points, const float *scale_weights, const float *occ2img,
                            int B, int Q, int T, int G, int P, int L, int N,
-                           float image_h, float image_w, float eps,
+                           float image_h, float image_w, float eps, int flags,
                            float *loc, float *weights, void *stream);
 
 /*
@@ -165,11 +169,13 @@ int opus_msmv_project_pack(const float *sample_points, const float *scale_weight
  * chosen camera's projection, and d scale_weights [B,Q,G,T,P,L] = d weights un-packed.
  * `loc` is the forward's output (it holds the chosen camera).  occ2img gets no gradient:
  * it is built from image metadata in the reference (models/opus_transformer.py:105-110).
+ * With OPUS_MSMV_PACK_SHARED_FRAMES the gradients have the shared shapes [B,Q,G,P,3] /
+ * [B,Q,G,P,L] and hold the sum over the T frames.
  */
 int opus_msmv_project_pack_backward(const float *dloc, const float *dweights,
                                     const float *sample_points, const float *occ2img, const float *loc,
                                     int B, int Q, int T, int G, int P, int L, int N,
-                                    float image_h, float image_w, float eps,
+                                    float image_h, float image_w, float eps, int flags,
                                     float *dsample_points, float *dscale_weights, void *stream);
 
 /*

@@ -15,6 +15,7 @@ OK = 0
 BWD_AUTO, BWD_ATOMIC, BWD_OWNER = 0, 1, 2
 BWD_ACCUMULATE = 0x10
 FWD_GENERIC = 0x1
+PACK_SHARED_FRAMES = 0x1
 BWD_STAGE_BIN, BWD_STAGE_DFEAT, BWD_STAGE_GATHER = 0x100, 0x200, 0x400
 MAX_LEVELS = 8
 MAX_POINTS = 32
@@ -51,10 +52,10 @@ SYMBOLS = {
            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_project_pack": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
-        + [ctypes.c_float] * 3 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+        + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "opus_msmv_project_pack_backward": (ctypes.c_int, [
         ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_float] * 3
-        + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+        + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "opus_msmv_relayout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8
                            + [ctypes.c_void_p]),
 }

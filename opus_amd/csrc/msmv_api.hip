@@ -260,37 +260,42 @@ static int check_project_dims(int B, int Q, int T, int G, int P, int L, int N)
 
 int opus_msmv_project_pack(const float *sample_points, const float *scale_weights, const float *occ2img,
                            int B, int Q, int T, int G, int P, int L, int N,
-                           float image_h, float image_w, float eps,
+                           float image_h, float image_w, float eps, int flags,
                            float *loc, float *weights, void *stream)
 {
     const int rc = check_project_dims(B, Q, T, G, P, L, N);
     if (rc != OPUS_MSMV_OK)
         return rc;
+    if (flags & ~OPUS_MSMV_PACK_SHARED_FRAMES)
+        return OPUS_MSMV_EINVAL_FLAGS;
     if ((long long)B * Q == 0)
         return OPUS_MSMV_OK;
     if (!sample_points || !scale_weights || !occ2img || !loc || !weights)
         return OPUS_MSMV_EINVAL_PTR;
     return msmv_launch_project_pack(sample_points, scale_weights, occ2img, B, Q, T, G, P, L, N,
-                                    image_h, image_w, eps, loc, weights, (hipStream_t)stream) == hipSuccess
+                                    image_h, image_w, eps, flags & OPUS_MSMV_PACK_SHARED_FRAMES, loc, weights,
+                                    (hipStream_t)stream) == hipSuccess
                ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
 }
 
 int opus_msmv_project_pack_backward(const float *dloc, const float *dweights,
                                     const float *sample_points, const float *occ2img, const float *loc,
                                     int B, int Q, int T, int G, int P, int L, int N,
-                                    float image_h, float image_w, float eps,
+                                    float image_h, float image_w, float eps, int flags,
                                     float *dsample_points, float *dscale_weights, void *stream)
 {
     const int rc = check_project_dims(B, Q, T, G, P, L, N);
     if (rc != OPUS_MSMV_OK)
         return rc;
+    if (flags & ~OPUS_MSMV_PACK_SHARED_FRAMES)
+        return OPUS_MSMV_EINVAL_FLAGS;
     if ((long long)B * Q == 0)
         return OPUS_MSMV_OK;
     if (!dloc || !dweights || !sample_points || !occ2img || !loc || !dsample_points || !dscale_weights)
         return OPUS_MSMV_EINVAL_PTR;
     return msmv_launch_project_pack_backward(dloc, dweights, sample_points, occ2img, loc, B, Q, T, G, P, L, N,
-                                             image_h, image_w, eps, dsample_points, dscale_weights,
-                                             (hipStream_t)stream) == hipSuccess
+                                             image_h, image_w, eps, flags & OPUS_MSMV_PACK_SHARED_FRAMES,
+                                             dsample_points, dscale_weights, (hipStream_t)stream) == hipSuccess
                ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
 }
 

@@ -18,12 +18,12 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
 // Caller-side fusion (msmv_project.hip): projection + view selection + packing, and its backward.
 hipError_t msmv_launch_project_pack(const float *pts, const float *sw, const float *occ2img,
                                     int B, int Q, int T, int G, int P, int L, int N,
-                                    float image_h, float image_w, float eps,
+                                    float image_h, float image_w, float eps, int shared,
                                     float *loc, float *w, hipStream_t s);
 hipError_t msmv_launch_project_pack_backward(const float *dloc, const float *dw, const float *pts,
                                              const float *occ2img, const float *loc,
                                              int B, int Q, int T, int G, int P, int L, int N,
-                                             float image_h, float image_w, float eps,
+                                             float image_h, float image_w, float eps, int shared,
                                              float *dpts, float *dsw, hipStream_t s);
 
 // Producer-side re-layout (msmv_relayout.hip): [B,T*N,G*C,H,W] <-> [B*T*G,N,H,W,C].

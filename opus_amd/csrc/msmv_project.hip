@@ -18,6 +18,7 @@ namespace {
 
 struct ProjDims {
     int B, Q, T, G, P, L, N;
+    int shared;          // the T frames share one set of points / weights: sources are [B,Q,G,P,*]
     float inv_w, inv_h, image_w, image_h, eps;
     long long npts;      // B*T*G*Q*P
 };
@@ -39,8 +40,14 @@ __device__ __forceinline__ ProjIndex proj_index(long long idx, const ProjDims &d
     r.g = (int)(x % d.G); x /= d.G;
     r.t = (int)(x % d.T); x /= d.T;
     r.b = (int)x;
-    r.src_pt = (((((size_t)r.b * d.Q + r.q) * d.T + r.t) * d.G + r.g) * d.P + r.p) * 3;
-    r.src_w = (((((size_t)r.b * d.Q + r.q) * d.G + r.g) * d.T + r.t) * d.P + r.p) * d.L;
+    if (d.shared) {
+        const size_t e = (((size_t)r.b * d.Q + r.q) * d.G + r.g) * d.P + r.p;
+        r.src_pt = e * 3;
+        r.src_w = e * d.L;
+    } else {
+        r.src_pt = (((((size_t)r.b * d.Q + r.q) * d.T + r.t) * d.G + r.g) * d.P + r.p) * 3;
+        r.src_w = (((((size_t)r.b * d.Q + r.q) * d.G + r.g) * d.T + r.t) * d.P + r.p) * d.L;
+    }
     r.dst_w = (((((size_t)r.b * d.G + r.g) * d.T + r.t) * d.Q + r.q) * d.P + r.p) * d.L;
     return r;
 }
@@ -116,9 +123,65 @@ msmv_project_pack_bwd(const float *__restrict__ dloc, const float *__restrict__ 
         dsw[ix.src_w + l] = dw[ix.dst_w + l];
 }
 
-ProjDims make_dims(int B, int Q, int T, int G, int P, int L, int N, float image_h, float image_w, float eps)
+// Backward when the frames share their points: one thread per source point (b, q, g, p) sums
+// the T frames' contributions (the expand of models/opus_transformer.py:353,358 run backwards).
+__global__ void __launch_bounds__(256)
+msmv_project_pack_bwd_shared(const float *__restrict__ dloc, const float *__restrict__ dw,
+                             const float *__restrict__ pts, const float *__restrict__ occ2img,
+                             const float *__restrict__ loc, ProjDims d,
+                             float *__restrict__ dpts, float *__restrict__ dsw)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nsrc = (long long)d.B * d.Q * d.G * d.P;
+    if (e >= nsrc)
+        return;
+    long long r = e;
+    const int p = (int)(r % d.P); r /= d.P;
+    const int g = (int)(r % d.G); r /= d.G;
+    const int q = (int)(r % d.Q);
+    const int b = (int)(r / d.Q);
+    const float x = pts[e * 3], y = pts[e * 3 + 1], z = pts[e * 3 + 2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    float gw[MSMV_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < MSMV_MAX_LEVELS; ++l)
+        gw[l] = 0.f;
+    for (int t = 0; t < d.T; ++t) {
+        const size_t idx = ((((size_t)b * d.T + t) * d.G + g) * d.Q + q) * d.P + p;       // loc slot
+        const size_t wrow = (((((size_t)b * d.G + g) * d.T + t) * d.Q + q) * d.P + p) * d.L;
+        int view = (int)roundf(loc[idx * 3 + 2] * (float)(d.N - 1));
+        view = min(max(view, 0), d.N - 1);
+        const float *M = occ2img + ((size_t)b * d.T * d.N + (size_t)t * d.N + view) * 16;
+        const float cx = M[0] * x + M[1] * y + M[2] * z + M[3];
+        const float cy = M[4] * x + M[5] * y + M[6] * z + M[7];
+        const float cz = M[8] * x + M[9] * y + M[10] * z + M[11];
+        const float hz = fmaxf(cz, d.eps);
+        const float du = dloc[idx * 3], dv = dloc[idx * 3 + 1];
+        const float gcx = du / (hz * d.image_w), gcy = dv / (hz * d.image_h);
+        const float ghz = -(gcx * cx + gcy * cy) / hz;
+        const float gcz = cz > d.eps ? ghz : 0.f;
+        gx += gcx * M[0] + gcy * M[4] + gcz * M[8];
+        gy += gcx * M[1] + gcy * M[5] + gcz * M[9];
+        gz += gcx * M[2] + gcy * M[6] + gcz * M[10];
+#pragma unroll
+        for (int l = 0; l < MSMV_MAX_LEVELS; ++l)
+            if (l < d.L)
+                gw[l] += dw[wrow + l];
+    }
+    dpts[e * 3] = gx;
+    dpts[e * 3 + 1] = gy;
+    dpts[e * 3 + 2] = gz;
+#pragma unroll
+    for (int l = 0; l < MSMV_MAX_LEVELS; ++l)
+        if (l < d.L)
+            dsw[e * d.L + l] = gw[l];
+}
+
+ProjDims make_dims(int B, int Q, int T, int G, int P, int L, int N, float image_h, float image_w, float eps,
+                   int shared)
 {
     ProjDims d;
+    d.shared = shared;
     d.B = B; d.Q = Q; d.T = T; d.G = G; d.P = P; d.L = L; d.N = N;
     d.image_w = image_w; d.image_h = image_h;
     d.inv_w = 1.f / image_w; d.inv_h = 1.f / image_h;
@@ -131,10 +194,10 @@ ProjDims make_dims(int B, int Q, int T, int G, int P, int L, int N, float image_
 
 hipError_t msmv_launch_project_pack(const float *pts, const float *sw, const float *occ2img,
                                     int B, int Q, int T, int G, int P, int L, int N,
-                                    float image_h, float image_w, float eps,
+                                    float image_h, float image_w, float eps, int shared,
                                     float *loc, float *w, hipStream_t s)
 {
-    const ProjDims d = make_dims(B, Q, T, G, P, L, N, image_h, image_w, eps);
+    const ProjDims d = make_dims(B, Q, T, G, P, L, N, image_h, image_w, eps, shared);
     if (d.npts == 0)
         return hipSuccess;
     const unsigned nblk = (unsigned)((d.npts + 255) / 256);
@@ -145,12 +208,18 @@ hipError_t msmv_launch_project_pack(const float *pts, const float *sw, const flo
 hipError_t msmv_launch_project_pack_backward(const float *dloc, const float *dw, const float *pts,
                                              const float *occ2img, const float *loc,
                                              int B, int Q, int T, int G, int P, int L, int N,
-                                             float image_h, float image_w, float eps,
+                                             float image_h, float image_w, float eps, int shared,
                                              float *dpts, float *dsw, hipStream_t s)
 {
-    const ProjDims d = make_dims(B, Q, T, G, P, L, N, image_h, image_w, eps);
+    const ProjDims d = make_dims(B, Q, T, G, P, L, N, image_h, image_w, eps, shared);
     if (d.npts == 0)
         return hipSuccess;
+    if (shared) {
+        const long long nsrc = (long long)B * Q * G * P;
+        hipLaunchKernelGGL(msmv_project_pack_bwd_shared, dim3((unsigned)((nsrc + 255) / 256)), dim3(256), 0, s,
+                           dloc, dw, pts, occ2img, loc, d, dpts, dsw);
+        return hipGetLastError();
+    }
     const unsigned nblk = (unsigned)((d.npts + 255) / 256);
     hipLaunchKernelGGL(msmv_project_pack_bwd, dim3(nblk), dim3(256), 0, s, dloc, dw, pts, occ2img, loc, d, dpts, dsw);
     return hipGetLastError();

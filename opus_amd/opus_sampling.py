@@ -130,16 +130,23 @@ class _ProjectPack(torch.autograd.Function):
     """opus_msmv_project_pack / _backward behind autograd (one kernel each way)."""
 
     @staticmethod
-    def forward(ctx, sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps):
+    def forward(ctx, sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps, num_frames=None):
         if not sample_points.is_cuda:
             raise RuntimeError("project_and_pack runs on the GPU only; "
                                "project_and_pack_torch is the tensor-op statement of it")
-        B, Q, T, G, P, three = sample_points.shape
-        assert three == 3
         L = scale_weights.shape[-1]
         N = int(num_views)
-        assert scale_weights.shape == (B, Q, G, T, P, L), "scale_weights must be [B,Q,G,T,P,L]"
+        shared = num_frames is not None       # one set of points / weights for all T frames
+        if shared:
+            B, Q, G, P, three = sample_points.shape
+            T = int(num_frames)
+            assert scale_weights.shape == (B, Q, G, P, L), "scale_weights must be [B,Q,G,P,L]"
+        else:
+            B, Q, T, G, P, three = sample_points.shape
+            assert scale_weights.shape == (B, Q, G, T, P, L), "scale_weights must be [B,Q,G,T,P,L]"
+        assert three == 3
         assert occ2img.shape == (B, T * N, 4, 4), "occ2img must be [B,T*N,4,4]"
+        flags = _lib.PACK_SHARED_FRAMES if shared else 0
         pts = sample_points.contiguous().float()
         sw = scale_weights.contiguous().float()
         mats = occ2img.contiguous().float()
@@ -149,28 +156,29 @@ class _ProjectPack(torch.autograd.Function):
         with torch.cuda.device(pts.device):
             _lib.check(lib.opus_msmv_project_pack(
                 _vp(pts), _vp(sw), _vp(mats), B, Q, T, G, P, L, N,
-                float(image_h), float(image_w), float(eps), _vp(loc), _vp(w),
+                float(image_h), float(image_w), float(eps), flags, _vp(loc), _vp(w),
                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "opus_msmv_project_pack")
         ctx.save_for_backward(pts, mats, loc)
-        ctx.dims = (B, Q, T, G, P, L, N, float(image_h), float(image_w), float(eps))
+        ctx.dims = (B, Q, T, G, P, L, N, float(image_h), float(image_w), float(eps), flags)
+        ctx.sw_shape = tuple(sw.shape)
         return loc, w
 
     @staticmethod
     def backward(ctx, dloc, dw):
         pts, mats, loc = ctx.saved_tensors
-        B, Q, T, G, P, L, N, image_h, image_w, eps = ctx.dims
+        B, Q, T, G, P, L, N, image_h, image_w, eps, flags = ctx.dims
         dloc = dloc.contiguous().float()
         dw = dw.contiguous().float()
         dpts = torch.empty_like(pts)
-        dsw = torch.empty((B, Q, G, T, P, L), dtype=torch.float32, device=pts.device)
+        dsw = torch.empty(ctx.sw_shape, dtype=torch.float32, device=pts.device)
         lib = _lib.load()
         with torch.cuda.device(pts.device):
             _lib.check(lib.opus_msmv_project_pack_backward(
                 _vp(dloc), _vp(dw), _vp(pts), _vp(mats), _vp(loc), B, Q, T, G, P, L, N,
-                image_h, image_w, eps, _vp(dpts), _vp(dsw),
+                image_h, image_w, eps, flags, _vp(dpts), _vp(dsw),
                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                 "opus_msmv_project_pack_backward")
-        return dpts, dsw, None, None, None, None, None
+        return dpts, dsw, None, None, None, None, None, None
 
 
 def project_pack_into(sample_points, scale_weights, occ2img, image_h, image_w, num_views, loc, weights,
@@ -185,7 +193,7 @@ def project_pack_into(sample_points, scale_weights, occ2img, image_h, image_w, n
     with torch.cuda.device(loc.device):
         _lib.check(_lib.load().opus_msmv_project_pack(
             _vp(sample_points), _vp(scale_weights), _vp(occ2img), B, Q, T, G, P, L, int(num_views),
-            float(image_h), float(image_w), float(eps), _vp(loc), _vp(weights),
+            float(image_h), float(image_w), float(eps), 0, _vp(loc), _vp(weights),
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "opus_msmv_project_pack")
 
 
@@ -200,15 +208,22 @@ def project_pack_backward_into(dloc, dweights, sample_points, occ2img, loc, imag
     with torch.cuda.device(loc.device):
         _lib.check(_lib.load().opus_msmv_project_pack_backward(
             _vp(dloc), _vp(dweights), _vp(sample_points), _vp(occ2img), _vp(loc), B, Q, T, G, P, L,
-            int(num_views), float(image_h), float(image_w), float(eps), _vp(dsample_points), _vp(dscale_weights),
+            int(num_views), float(image_h), float(image_w), float(eps), 0, _vp(dsample_points),
+            _vp(dscale_weights),
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "opus_msmv_project_pack_backward")
 
 
-def project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5):
+def project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5,
+                     num_frames=None):
     """Same result as ``project_and_pack_torch`` from one HIP kernel (and one for the
     backward): (loc [B*T*G, Q, P, 3], weights [B*G*T, Q, P, L]).  occ2img gets no gradient
-    (the reference builds it from image metadata, models/opus_transformer.py:105-110)."""
-    return _ProjectPack.apply(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps)
+    (the reference builds it from image metadata, models/opus_transformer.py:105-110).
+
+    ``num_frames=T``: the frames share their points and weights - sample_points [B,Q,G,P,3] and
+    scale_weights [B,Q,G,P,L], i.e. what the decoder has BEFORE it expands them over T
+    (models/opus_transformer.py:350-358); their gradients then come back summed over the frames."""
+    return _ProjectPack.apply(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps,
+                              num_frames)
 
 
 def unpack(final, B, T, G):
@@ -219,11 +234,18 @@ def unpack(final, B, T, G):
 
 
 def sampling_4d(sample_points, mlvl_feats, scale_weights, occ2img, image_h, image_w, num_views=6, eps=1e-5,
-                fused=True):
+                fused=True, num_frames=None):
     """Same contract as the reference's sampling_4d with channel-last features
     [B*T*G, N, H, W, C]; returns [B, Q, G, T*P, C].  ``fused=False`` runs the projection and
     the un-pack as the reference's tensor ops around the plain op (same result, for
     comparison)."""
+    if num_frames is not None:
+        # un-expanded inputs ([B,Q,G,P,3] / [B,Q,G,P,L], see project_and_pack): fused path only
+        assert fused, "num_frames needs the fused path"
+        B, Q, G, P, _ = sample_points.shape
+        loc, w = project_and_pack(sample_points, scale_weights, occ2img, image_h, image_w, num_views, eps,
+                                  num_frames)
+        return msmv_sampling_rows(mlvl_feats, loc, w, int(num_frames), G)
     B, Q, T, G, P, _ = sample_points.shape
     if fused:
         # two launches forward (project + pack, then the op writing [B,Q,G,T*P,C] directly);

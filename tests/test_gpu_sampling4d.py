@@ -376,3 +376,36 @@ def test_project_pack_randomised_shapes(ops):
         ok = (err <= 1e-5 * scale) | (err <= 5e-3 * np.abs(ref_dpts))
         assert np.isfinite(got).all() and ok.all(), f"{what} d sample_points: max|diff| {err[~ok].max():.3e}"
         assert np.array_equal(d_sw.grad.cpu().numpy(), ref_dsw), what
+
+
+def test_shared_frames_equal_the_expanded_inputs(ops):
+    """The decoder expands one set of points / weights over the T frames before it calls
+    sampling_4d (models/opus_transformer.py:350-358).  Feeding the un-expanded tensors with
+    num_frames=T must give the same output, and gradients equal to autograd's sum over T."""
+    B, Q, T, G, P, N, L, C = 1, 40, 4, 2, 3, 6, 4, 64
+    H, W = 256, 704
+    pts, sw, occ2img = sampling4d_case(91, B, Q, T, G, P, N, L, H, W)
+    base_pts, base_sw = pts[:, :, 0].copy(), sw[:, :, :, 0].copy()          # [B,Q,G,P,3], [B,Q,G,P,L]
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    feats0 = [torch.randn((B * T * G, N, h, w_, C), generator=gen, device="cuda") for h, w_ in REAL_LEVELS]
+    gout = torch.randn((B, Q, G, T * P, C), generator=gen, device="cuda")
+
+    def run(shared):
+        p0, s0 = dev(base_pts).requires_grad_(True), dev(base_sw).requires_grad_(True)
+        feats = [f.clone().requires_grad_(True) for f in feats0]
+        if shared:
+            out = ops.sampling_4d(p0, feats, s0, dev(occ2img), H, W, N, num_frames=T)
+        else:
+            pe = p0[:, :, None].expand(B, Q, T, G, P, 3)
+            se = s0[:, :, :, None].expand(B, Q, G, T, P, L)
+            out = ops.sampling_4d(pe, feats, se, dev(occ2img), H, W, N)
+        out.backward(gout)
+        return out.detach(), p0.grad, s0.grad, [f.grad for f in feats]
+
+    out_a, dp_a, ds_a, df_a = run(True)
+    out_b, dp_b, ds_b, df_b = run(False)
+    assert torch.equal(out_a, out_b)
+    assert_close(dp_a.cpu().numpy(), dp_b.cpu().numpy(), 1e-5, "d sample_points (summed over frames)")
+    assert_close(ds_a.cpu().numpy(), ds_b.cpu().numpy(), 1e-5, "d scale_weights (summed over frames)")
+    for a_, b_ in zip(df_a, df_b):
+        assert_close(a_.cpu().numpy(), b_.cpu().numpy(), GRAD_RTOL, "d feats")

@@ -80,10 +80,11 @@ def test_argument_validation_returns_before_any_launch(lib):
     assert lib.opus_msmv_relayout(null, null, 1, 8, 6, 4, 64, 4, 4, 0, null) == -4
     assert lib.opus_msmv_relayout(null, null, 0, 8, 6, 4, 64, 4, 4, 0, null) == 0
     pp = lib.opus_msmv_project_pack
-    assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 1, 256.0, 704.0, 1e-5, null, null, null) == -3   # N < 2
-    assert pp(null, null, null, 1, 4, 8, 4, 33, 4, 6, 256.0, 704.0, 1e-5, null, null, null) == -2
-    assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, null, null, null) == -4
-    assert pp(null, null, null, 1, 0, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, null, null, null) == 0
+    assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 1, 256.0, 704.0, 1e-5, 0, null, null, null) == -3   # N < 2
+    assert pp(null, null, null, 1, 4, 8, 4, 33, 4, 6, 256.0, 704.0, 1e-5, 0, null, null, null) == -2
+    assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 1, null, null, null) == -4
+    assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 2, null, null, null) == -7   # unknown flag
+    assert pp(null, null, null, 1, 0, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 0, null, null, null) == 0
     assert n >= 32 * 4800 * 2 * 32 and n < 32 * 4800 * 2 * 32 + (1 << 20)
 
 

@@ -84,6 +84,27 @@ def main():
             out = opus_sampling.sampling_4d(pts, feats, sw, occ2img, H, W, N, fused=fused)
             out.backward(gout)
         res[f"sampling_4d_fwdbwd_us_{name}"] = timed(chain, max(args.iters // 2, 5))
+    # what the decoder really hands over: ONE set of points / weights, expanded over the frames
+    # (models/opus_transformer.py:350-358) - as expanded views, and un-expanded with num_frames
+    bp = pts.detach()[:, :, 0].contiguous().requires_grad_(True)             # [B,Q,G,P,3]
+    bs = sw.detach()[:, :, :, 0].contiguous().requires_grad_(True)           # [B,Q,G,P,L]
+
+    def chain_expanded():
+        bp.grad = bs.grad = None
+        for f in feats:
+            f.grad = None
+        out = opus_sampling.sampling_4d(bp[:, :, None].expand(B, Q, T, G, P, 3), feats,
+                                        bs[:, :, :, None].expand(B, Q, G, T, P, L), occ2img, H, W, N)
+        out.backward(gout)
+
+    def chain_shared():
+        bp.grad = bs.grad = None
+        for f in feats:
+            f.grad = None
+        opus_sampling.sampling_4d(bp, feats, bs, occ2img, H, W, N, num_frames=T).backward(gout)
+    res["sampling_4d_fwdbwd_us_fused_expanded_views"] = timed(chain_expanded, max(args.iters // 2, 5))
+    res["sampling_4d_fwdbwd_us_fused_shared_frames"] = timed(chain_shared, max(args.iters // 2, 5))
+
     # the op alone, in its own output layout + the caller's permute copy, against row mode
     with torch.no_grad():
         loc, w = opus_sampling.project_and_pack(pts, sw, occ2img, H, W, N)
