@@ -418,6 +418,11 @@ def main():
                     "achieved": dom.get("achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": (dom["achieved_GBps"] / HBM_PEAK_GBPS) if "achieved_GBps" in dom else None,
                     "traffic": load_traffic(wl, dominant),
+                    # what actually crossed the HBM interface, as a rate (PMC bytes / launch time)
+                    "traffic_GBps": (load_traffic(wl, dominant) / (dom["avg_us"] * 1e-6) / 1e9)
+                    if load_traffic(wl, dominant) else None,
+                    "traffic_frac": (load_traffic(wl, dominant) / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS)
+                    if load_traffic(wl, dominant) else None,
                     "alg_bytes_per_launch": dom.get("alg_bytes"), "avg_launch_us": dom["avg_us"],
                     "note": "achieved = algorithmic (no-reuse) bytes / HIP-event launch time; "
                             "features re-touched by several points are served from L2 / Infinity Cache"}
