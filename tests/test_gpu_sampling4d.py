@@ -409,3 +409,36 @@ def test_shared_frames_equal_the_expanded_inputs(ops):
     assert_close(ds_a.cpu().numpy(), ds_b.cpu().numpy(), 1e-5, "d scale_weights (summed over frames)")
     for a_, b_ in zip(df_a, df_b):
         assert_close(a_.cpu().numpy(), b_.cpu().numpy(), GRAD_RTOL, "d feats")
+
+
+def test_feature_grad_sink_under_activation_checkpointing(ops):
+    """The reference wraps every sampling layer in torch.utils.checkpoint (use_reentrant=False,
+    models/opus_transformer.py:372-375): the forward is recomputed inside the backward.  The shared
+    d-feat buffer must still receive each layer exactly once."""
+    from torch.utils.checkpoint import checkpoint
+    from opus_amd.csrc import wrapper as wr
+    B, N, C, Q, P, T, G = 4, 6, 64, 30, 2, 2, 2
+    feats, _, _, _ = random_case(700, REAL_LEVELS, B, N, C, Q, P)
+    layers = [random_case(701 + i, TINY_LEVELS, B, N, 1, Q, P)[1:3] for i in range(3)]
+    gen = torch.Generator(device="cuda")
+
+    def run(use_sink, use_checkpoint):
+        f = [dev(x).requires_grad_(True) for x in feats]
+        lw = [(dev(l).requires_grad_(True), dev(w).requires_grad_(True)) for l, w in layers]
+        src = wr.FeatureGradSink(f) if use_sink else f
+        gen.manual_seed(1)
+        total = 0
+        for l, w in lw:
+            fn = lambda l_, w_: wr.msmv_sampling_rows(src, l_, w_, T, G)          # noqa: E731
+            out = checkpoint(fn, l, w, use_reentrant=False) if use_checkpoint else fn(l, w)
+            total = total + (out * torch.randn(out.shape, generator=gen, device="cuda")).sum()
+        total.backward()
+        return f, lw
+
+    f_ref, lw_ref = run(False, False)
+    f_chk, lw_chk = run(True, True)
+    for i, (a, b) in enumerate(zip(f_chk, f_ref)):
+        assert_close(a.grad.cpu().numpy(), b.grad.cpu().numpy(), GRAD_RTOL, f"dfeat{i}, sink + checkpoint")
+    for (la, wa), (lb, wb) in zip(lw_chk, lw_ref):
+        assert_close(la.grad.cpu().numpy(), lb.grad.cpu().numpy(), 1e-5, "dloc")
+        assert_close(wa.grad.cpu().numpy(), wb.grad.cpu().numpy(), 1e-5, "dw")
