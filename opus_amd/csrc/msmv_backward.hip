@@ -294,6 +294,86 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
     }
 }
 
+// Small slabs (at most BIN_ONE_PPT * BIN_THREADS points, e.g. OPUS-T / S): the whole counting
+// sort of a slab in ONE workgroup and one launch - histogram, scan and placement in LDS, no
+// global counters, nothing to clear beforehand.  Three launches' worth of latency is most of
+// the two-pass sort's time at these sizes.
+constexpr int BIN_ONE_PPT = 3;
+__global__ void __launch_bounds__(BIN_THREADS)
+msmv_bin_one(const MsmvArgs a, OwnerWs ws)
+{
+    __shared__ int hist[BIN_MAX_KEYS];
+    __shared__ int scan[2][BIN_MAX_KEYS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int keys = ws.keys;
+    for (int k = tid; k < keys; k += BIN_THREADS)
+        hist[k] = 0;
+    __syncthreads();
+    int key[BIN_ONE_PPT], rank[BIN_ONE_PPT];
+    float x[BIN_ONE_PPT], y[BIN_ONE_PPT];
+#pragma unroll
+    for (int u = 0; u < BIN_ONE_PPT; ++u) {
+        const int i = u * BIN_THREADS + tid;
+        key[u] = -1;
+        rank[u] = 0;
+        x[u] = y[u] = 0.f;
+        if (i < a.qp) {
+            const float *lp = a.loc + ((size_t)b * a.qp + i) * 3;
+            x[u] = lp[0];
+            y[u] = lp[1];
+            key[u] = msmv_bin_key(lp, a.N);
+            if (key[u] >= 0)
+                rank[u] = atomicAdd(&hist[key[u]], 1);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < keys; k += BIN_THREADS)
+        scan[0][k] = hist[k];
+    int cur = 0;
+    for (int d = 1; d < keys; d <<= 1) {                       // inclusive Hillis-Steele scan
+        __syncthreads();
+        for (int k = tid; k < keys; k += BIN_THREADS)
+            scan[cur ^ 1][k] = scan[cur][k] + (k >= d ? scan[cur][k - d] : 0);
+        cur ^= 1;
+    }
+    __syncthreads();
+    int *off = ws.offsets + (size_t)b * (keys + 1);
+    for (int k = tid; k < keys; k += BIN_THREADS) {
+        const int excl = scan[cur][k] - hist[k];
+        off[k] = excl;
+        if (k == keys - 1)
+            off[keys] = scan[cur][k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BIN_ONE_PPT; ++u) {
+        const int i = u * BIN_THREADS + tid;
+        const size_t pt = (size_t)b * a.qp + i;
+        if (i < a.qp && key[u] < 0) {
+            // no valid view: in no bin, zero gradients (the bin-ordered gather never sees it)
+            float *dl = a.dloc + pt * 3;
+            dl[0] = 0.f; dl[1] = 0.f; dl[2] = 0.f;
+            for (int k = 0; k < a.L; ++k)
+                a.dw[pt * a.L + k] = 0.f;
+        }
+        if (key[u] >= 0) {
+            const float *wp = a.w + pt * a.L;
+            float wv[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                wv[k] = k < a.L ? wp[k] : 0.f;
+            if (a.L <= 4)
+                wv[4] = __int_as_float(key[u] / BIN_PER_VIEW);     // the view, for the gather pass
+            const int pos = scan[cur][key[u]] - hist[key[u]] + rank[u];
+            float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + pos);
+            const int id = a.rows ? msmv_row_of((int)pt, a) : (int)pt;
+            e[0] = make_float4(__int_as_float(id), x[u], y[u], wv[0]);
+            e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
+        }
+    }
+}
+
 // ======================================================================================
 // owner algorithm: d feat tiles
 // ======================================================================================
@@ -1085,7 +1165,11 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N));
 
     hipError_t e;
-    if (stages & 1) {
+    if ((stages & 1) && a.qp > 0 && a.qp <= BIN_ONE_PPT * BIN_THREADS) {
+        hipLaunchKernelGGL(msmv_bin_one, dim3((unsigned)a.B), dim3(BIN_THREADS), 0, s, a, ws);
+        if ((e = hipGetLastError()) != hipSuccess)
+            return e;
+    } else if (stages & 1) {
         if ((e = hipMemsetAsync(workspace, 0, owner_ws_clear_bytes(a.B, a.N), s)) != hipSuccess)
             return e;
         if (ws.chunks > 0) {
