@@ -443,7 +443,7 @@ typedef __attribute__((address_space(3))) void *msmv_lptr_t;
 #define MSMV_OWN_STAGED 1
 #endif
 #ifndef MSMV_OWN_STAGE_F4
-#define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave: 8 waves' areas + queues = 40 KiB, 3-4 workgroups per CU
+#define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave (with the queue 4.5 KiB): LDS never limits the occupancy
 #endif
 #ifndef MSMV_OWN_OCC
 #define MSMV_OWN_OCC 4, 8

@@ -136,7 +136,7 @@ def test_hot_spot_thousands_of_points_in_one_patch(wr, oracle):
 
 
 def test_patches_shared_by_several_waves(wr, oracle):
-    """Many points on small levels: the owner kernel puts 2, 4 or 8 waves on one patch (each
+    """Many points on small levels: the owner kernel puts 2 or 4 waves on one patch (each
     takes every K-th bin entry) and sums their partial tiles; includes ragged patches, slabs
     whose patch count is not a multiple of the patches per workgroup, and accumulate mode."""
     for levels, Q in (([(8, 22), (4, 11), (2, 6), (1, 3)], 2000), ([(16, 44), (8, 22), (5, 13), (3, 3)], 1200)):
