@@ -59,6 +59,10 @@ def parse_args():
                          "points in all 8 frames)")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU (B' = 32 * batch)")
     ap.add_argument("--bwd-algo", default="owner", choices=["owner", "atomic"])
+    ap.add_argument("--dfeat", default="deferred", choices=["deferred", "accumulate"],
+                    help="decoder workloads: how the layers' d feats are summed - 'deferred': every layer sorts "
+                         "and gathers, one d-feat pass over all layers at the end writes d feats once; "
+                         "'accumulate': the first layer's backward writes them, the others add to them")
     ap.add_argument("--split-sample", action="store_true",
                     help="single-sample latency mode: the 32*batch slabs are split across the ranks (strong "
                          "scaling, still no data-path collective) instead of one whole batch per rank")
@@ -185,9 +189,12 @@ def alg_bytes(npts, feat_bytes):
 class Step:
     """One decoder layer's forward (+ backward) with an event pair around every launch."""
 
-    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1, caller=None):
+    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1, caller=None, defer=False):
         self.feats, self.sets, self.do_bwd, self.n_fwd = feats, sets, do_bwd, n_fwd
         self.algo = algo
+        # deferred d feats: every layer sorts and gathers into a workspace of its own, one
+        # d-feat pass over all layers closes the step (opus_msmv_dfeat_multi)
+        self.defer = defer and do_bwd and algo == "owner" and len(sets) > 1
         # caller = list of (sample_points, scale_weights, occ2img), one per set: the step then
         # includes the projection kernels and the op runs in row mode ([B,Q,G,T*P,C] tensors)
         self.caller = caller
@@ -201,6 +208,7 @@ class Step:
         flags = _lib.BWD_OWNER if algo == "owner" else _lib.BWD_ATOMIC
         need = wrapper.backward_workspace_bytes(feats, loc, w, flags)
         self.ws = torch.empty(max(need, 16), dtype=torch.uint8, device=loc.device)
+        self.ws_per_layer = [torch.empty_like(self.ws) for _ in sets] if self.defer else None
         self.events = []          # (kernel name, start, end)
         self._boundary = None
 
@@ -236,7 +244,16 @@ class Step:
             if not self.do_bwd:
                 continue
             args = (g, self.feats, loc, w, self.dfeats, self.dloc, self.dw, self.ws)
-            if self.algo == "owner" and not record:
+            if self.defer:
+                dargs = (g, self.feats, loc, w, None, self.dloc, self.dw, self.ws_per_layer[layer])
+                if not record:
+                    wrapper.msmv_backward_into(*dargs, flags=_lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER,
+                                               rows=rows)
+                else:
+                    for name, bit in (("msmv_bin_sort", _lib.BWD_STAGE_BIN), ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
+                        self._timed(name, lambda bit=bit: wrapper.msmv_backward_into(
+                            *dargs, flags=_lib.BWD_OWNER | bit, rows=rows), record)
+            elif self.algo == "owner" and not record:
                 # the product path: one call issues the sort, the d-feat and the gather kernels
                 wrapper.msmv_backward_into(*args, flags=_lib.BWD_OWNER | acc, rows=rows)
             elif self.algo == "owner":
@@ -253,6 +270,14 @@ class Step:
             if self.caller:
                 self._timed("msmv_project_pack_bwd", lambda: opus_sampling.project_pack_backward_into(
                     self.dloc, self.dw, pts, occ2img, loc, 256, 704, N_VIEWS, self.dpts, self.dsw), record)
+        if self.defer:
+            _, Q, P, _ = self.sets[0][0].shape
+            cap = _lib.load().opus_msmv_dfeat_max_sets()
+            for i in range(0, len(self.sets), cap):
+                part = range(i, min(i + cap, len(self.sets)))
+                self._timed(f"msmv_bwd_owner_dfeat({len(part)} layers)", lambda: wrapper.msmv_dfeat_multi(
+                    [self.sets[k][2] for k in part], [self.ws_per_layer[k] for k in part], self.feats, Q, P,
+                    self.dfeats, rows=self.rows, accumulate=i > 0), record)
 
     def kernel_ms(self):
         """name -> (mean, launches, p10, p50, p90) in ms."""
@@ -356,7 +381,7 @@ def main():
         if wl.startswith("sampling4d-"):
             caller = cam
             sets = [(loc, w, g.reshape(args.batch, Q, 4, 8 * P, CHANNELS)) for loc, w, g in sets]
-    step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd, caller=caller)
+    step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd, caller=caller, defer=args.dfeat == "deferred")
     npts_step = Bp * Q * P * n_layers                    # sampled points per step per rank
     feat_bytes = sum(f.numel() * 4 for f in feats)
 
@@ -456,6 +481,7 @@ def main():
                        "name": wl, "Q": Q, "P": P, "slabs_per_gpu": Bp, "views": N_VIEWS,
                        "levels": LEVELS, "channels": CHANNELS,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
+                       "dfeat_sum": ("deferred" if step.defer else "accumulate") if n_layers > 1 and do_bwd else None,
                        "points": args.points if (not caller or args.points != "uniform") else "cameras",
                        "launch": "HIP graph replay" if args.graph else
                                  f"one call per kernel; HIP events between them in every {args.event_every}. timed step",

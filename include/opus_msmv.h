@@ -145,6 +145,28 @@ int opus_msmv_backward_rows(int L, const float *grad_out, const float *const *fe
                             void *workspace, size_t workspace_bytes, int flags, void *stream);
 
 /*
+ * Deferred d feats for a stack of layers that sample the same feature maps (the decoder calls
+ * the op once per layer, models/opus_transformer.py:57-75, and autograd sums the layers'
+ * 735 MB d feats; nothing in a layer's own backward reads them).  No counterpart in the
+ * reference.  Each layer's backward runs only OPUS_MSMV_BWD_OWNER | OPUS_MSMV_BWD_STAGE_BIN |
+ * OPUS_MSMV_BWD_STAGE_GATHER (its d loc / d weights; `dfeats` may then be NULL) into a
+ * workspace of its own and keeps that workspace and its grad_out alive; after the last layer
+ * ONE call of opus_msmv_dfeat_multi() accumulates all of them, so that d feats are written
+ * once instead of once per layer (and never read back):
+ *   nsets in [1, opus_msmv_dfeat_max_sets()] sets, all of the same sizes; grad_outs[i] is
+ *   [B,Q,C,P] (T == 0, B = Bs) or [Bs,Q,G,T*P,C] (T >= 1, row mode); workspaces[i] (each of
+ *   workspace_bytes >= opus_msmv_backward_workspace_bytes()) holds set i's sort.
+ *   flags: 0 (d feats are overwritten, every element) or OPUS_MSMV_BWD_ACCUMULATE (for a
+ *   further batch of sets).  EINVAL_FLAGS where the owner algorithm does not apply (C != 64,
+ *   L outside {4,5}, pointers not 16-byte aligned).
+ */
+int opus_msmv_dfeat_max_sets(void);
+int opus_msmv_dfeat_multi(int L, int nsets, const float *const *grad_outs, void *const *workspaces,
+                          size_t workspace_bytes, const int *hw,
+                          int Bs, int T, int G, int C, int N, int Q, int P,
+                          float *const *dfeats, int flags, void *stream);
+
+/*
  * Caller-side fusion: everything sampling_4d does before it calls the op
  * (models/opus_sampling.py:36-113), in one launch.
  *   sample_points [B,Q,T,G,P,3] (metres), scale_weights [B,Q,G,T,P,L], occ2img [B,T*N,4,4]

@@ -50,6 +50,11 @@ SYMBOLS = {
         ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
         + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "opus_msmv_dfeat_max_sets": (ctypes.c_int, []),
+    "opus_msmv_dfeat_multi": (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+        ctypes.c_size_t, _i32p] + [ctypes.c_int] * 7
+        + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_project_pack": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
         + [ctypes.c_float] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

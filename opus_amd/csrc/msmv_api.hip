@@ -182,13 +182,15 @@ static int backward_impl(int L, const float *grad_out, const float *const *feats
         return OPUS_MSMV_EINVAL_FLAGS;
     if (stage_bits && algo != OPUS_MSMV_BWD_OWNER)
         return OPUS_MSMV_EINVAL_FLAGS;
-    if (!feats || !dfeats)
+    // d feats may be absent when the stages asked for leave them alone (sort and / or gather only)
+    const bool need_dfeat = algo != OPUS_MSMV_BWD_OWNER || !stage_bits || (stage_bits & OPUS_MSMV_BWD_STAGE_DFEAT);
+    if (!feats || (need_dfeat && !dfeats))
         return OPUS_MSMV_EINVAL_PTR;
     for (int l = 0; l < L; ++l) {
-        if (B > 0 && (!feats[l] || !dfeats[l]))
+        if (B > 0 && (!feats[l] || (need_dfeat && !dfeats[l])))
             return OPUS_MSMV_EINVAL_PTR;
         a.lvl[l].feat = feats[l];
-        a.lvl[l].dfeat = dfeats[l];
+        a.lvl[l].dfeat = dfeats ? dfeats[l] : nullptr;
     }
     if (a.npts > 0 && (!grad_out || !loc || !weights || !dloc || !dweights))
         return OPUS_MSMV_EINVAL_PTR;
@@ -243,6 +245,55 @@ int opus_msmv_backward_rows(int L, const float *grad_out, const float *const *fe
         return OPUS_MSMV_EINVAL_DIMS;
     return backward_impl(L, grad_out, feats, hw, loc, weights, Bs * T * G, T, G, C, N, Q, P, dfeats, dloc, dweights,
                          workspace, workspace_bytes, flags, stream);
+}
+
+int opus_msmv_dfeat_max_sets(void) { return msmv_dfeat_max_sets(); }
+
+int opus_msmv_dfeat_multi(int L, int nsets, const float *const *grad_outs, void *const *workspaces,
+                          size_t workspace_bytes, const int *hw,
+                          int Bs, int T, int G, int C, int N, int Q, int P,
+                          float *const *dfeats, int flags, void *stream)
+{
+    int B = Bs;
+    if (T) {
+        if (Bs < 0 || T < 1 || G < 1 || (long long)Bs * T * G > INT_MAX)
+            return OPUS_MSMV_EINVAL_DIMS;
+        B = Bs * T * G;
+    }
+    MsmvArgs a = {};
+    int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    if (rc == OPUS_MSMV_OK && T)
+        rc = fill_rows(a, T, G);
+    if (rc != OPUS_MSMV_OK)
+        return rc;
+    if (flags & ~OPUS_MSMV_BWD_ACCUMULATE)
+        return OPUS_MSMV_EINVAL_FLAGS;
+    if (nsets < 1 || nsets > msmv_dfeat_max_sets())
+        return OPUS_MSMV_EINVAL_DIMS;
+    if (!msmv_backward_owner_supported(a))
+        return OPUS_MSMV_EINVAL_FLAGS;          // the sorted sets exist for the owner algorithm only
+    if (B == 0)
+        return OPUS_MSMV_OK;
+    if (!grad_outs || !workspaces || !dfeats)
+        return OPUS_MSMV_EINVAL_PTR;
+    for (int l = 0; l < L; ++l) {
+        if (!dfeats[l])
+            return OPUS_MSMV_EINVAL_PTR;
+        if (!aligned16(dfeats[l]))
+            return OPUS_MSMV_EINVAL_FLAGS;
+        a.lvl[l].dfeat = dfeats[l];
+    }
+    if (workspace_bytes < msmv_backward_owner_workspace(B, N, Q, P))
+        return OPUS_MSMV_EWORKSPACE;
+    for (int i = 0; i < nsets; ++i) {
+        if (!workspaces[i] || (a.npts > 0 && !grad_outs[i]))
+            return OPUS_MSMV_EINVAL_PTR;
+        if (!aligned16(workspaces[i]) || !aligned16(grad_outs[i]))
+            return OPUS_MSMV_EINVAL_FLAGS;
+    }
+    const hipError_t e = msmv_launch_dfeat_sets(a, nsets, grad_outs, workspaces, (hipStream_t)stream,
+                                                (flags & OPUS_MSMV_BWD_ACCUMULATE) != 0);
+    return e == hipSuccess ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
 }
 
 static int check_project_dims(int B, int Q, int T, int G, int P, int L, int N)

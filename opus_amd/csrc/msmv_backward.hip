@@ -433,6 +433,17 @@ struct OwnerGeom {
     int tiles_per_b;                         // N * sum over levels
 };
 
+// The sorted point sets one d-feat launch accumulates: normally one (this call's), several when
+// a stack of layers that sample the same feature maps defers its d feats to one pass - d feat
+// is then written once instead of once per layer.  All sets share the sizes in MsmvArgs.
+constexpr int OWN_MAX_SETS = 8;
+struct OwnerSets {
+    const float *gout[OWN_MAX_SETS];        // gradient of the op's output, per set
+    const int *offsets[OWN_MAX_SETS];       // OwnerWs::offsets of the set's sort
+    const BinEntry *entries[OWN_MAX_SETS];  // OwnerWs::entries
+    int n;
+};
+
 typedef float msmv_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(1))) const void *msmv_gptr_t;
 typedef __attribute__((address_space(3))) void *msmv_lptr_t;
@@ -456,22 +467,22 @@ template <int PT>
 struct GradRaw { float v[PT == 0 ? 2 : 2 * PT]; };
 
 template <int PT>
-__device__ __forceinline__ GradRaw<PT> msmv_load_grad(const MsmvArgs &a, int pt, int l32)
+__device__ __forceinline__ GradRaw<PT> msmv_load_grad(const MsmvArgs &a, const float *gout, int pt, int l32)
 {
     GradRaw<PT> r;
     if constexpr (PT == 0) {
         const int bq = pt / a.P, p = pt - bq * a.P;
-        const float *gp = a.gout + ((size_t)bq * 64 + l32 * 2) * a.P + p;
+        const float *gp = gout + ((size_t)bq * 64 + l32 * 2) * a.P + p;
         r.v[0] = gp[0];
         r.v[1] = gp[(size_t)a.P];
     } else if constexpr (PT == 1) {
-        const float2 t = *reinterpret_cast<const float2 *>(a.gout + (size_t)pt * 64 + l32 * 2);
+        const float2 t = *reinterpret_cast<const float2 *>(gout + (size_t)pt * 64 + l32 * 2);
         r.v[0] = t.x; r.v[1] = t.y;
     } else if constexpr (PT == 2) {
-        const float4 t = *reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 1) * 64 + l32 * 2) * 2);
+        const float4 t = *reinterpret_cast<const float4 *>(gout + ((size_t)(pt >> 1) * 64 + l32 * 2) * 2);
         r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
     } else {
-        const float4 *gp = reinterpret_cast<const float4 *>(a.gout + ((size_t)(pt >> 2) * 64 + l32 * 2) * 4);
+        const float4 *gp = reinterpret_cast<const float4 *>(gout + ((size_t)(pt >> 2) * 64 + l32 * 2) * 4);
         const float4 t = gp[0], u = gp[1];
         r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
         r.v[4] = u.x; r.v[5] = u.y; r.v[6] = u.z; r.v[7] = u.w;
@@ -539,9 +550,11 @@ struct OwnHit {
 // ACC: add the patch to what d feat already holds instead of overwriting it (one decoder
 // layer after another accumulating into one buffer); a patch that no point reaches is then
 // left alone.
-template <int PT, bool ACC>
+// MULTI: more than one point set (the loop over sets costs registers, hence occupancy: the
+// single-set kernel is compiled without it).
+template <int PT, bool ACC, bool MULTI>
 __global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(MSMV_OWN_OCC)))
-msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
+msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
 {
     constexpr int GP = PT == 4 ? 1 : OWN_GROUP;      // P = 4 fetches 32 B per lane and record
     static_assert(OWN_QCAP % (4 * GP) == 0 && OWN_QCAP <= 64, "queue rounds are consumed in whole groups");
@@ -603,8 +616,11 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
     msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, geo.div_wm1[l], xb_lo, xb_hi);
     const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
     const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB
-    const int *off = ws.offsets + (size_t)b * (ws.keys + 1) + view * BIN_PER_VIEW;
-    const float4 *list = reinterpret_cast<const float4 *>(ws.entries + (size_t)b * a.qp);
+    int total_sets = 0;                                      // entries of the patch's bins over all sets
+    for (int set = 0; set < (MULTI ? sets.n : 1); ++set) {
+    const float *gout = sets.gout[set];
+    const int *off = sets.offsets[set] + (size_t)b * (a.N * BIN_PER_VIEW + 1) + view * BIN_PER_VIEW;
+    const float4 *list = reinterpret_cast<const float4 *>(sets.entries[set] + (size_t)b * a.qp);
 
     // Lane s holds segment s: its length, the count of entries before it (excl) and
     // delta = begin - excl, so that virtual entry v of the concatenation is list[v + delta].
@@ -734,7 +750,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                     for (int i = 0; i < MAXI; ++i) {
                         if (i < ninstr) {                              // wave-uniform
                             const int row = PT == 4 ? rpt[i] >> 2 : PT == 2 ? rpt[i] >> 1 : rpt[i];
-                            const float *src = a.gout + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
+                            const float *src = gout + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
                             __builtin_amdgcn_global_load_lds((msmv_gptr_t)src, (msmv_lptr_t)(stage + i * 64), 16, 0, 0);
                         }
                     }
@@ -779,7 +795,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
                 _Pragma("unroll") for (int u = 0; u < GP; ++u) {                             \
                     const float *q = reinterpret_cast<const float *>(queue + (((G) * GP + u) * 2 + half) * 2); \
                     X##_pt[u] = __float_as_int(q[0]);                                         \
-                    X##_g[u] = msmv_load_grad<PT>(a, X##_pt[u], l32);                        \
+                    X##_g[u] = msmv_load_grad<PT>(a, gout, X##_pt[u], l32);                  \
                 }
 #define MSMV_OWN_APPLY(X, G)                                                                  \
                 _Pragma("unroll") for (int u = 0; u < GP; ++u) {                             \
@@ -818,6 +834,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
             }
         }
     }
+    total_sets += total;
+    }   // sets
 
     // ---- K > 1: sum the K partial tiles of a patch, halving the live waves per round.  The
     // round count is the workgroup's (one level, one K): every wave reaches every barrier.
@@ -848,7 +866,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerWs ws, OwnerGeom geo)
         return;
     if constexpr (ACC) {
         if (K > 1)
-            any_hit = total > 0;         // (a patch whose bins hold entries but no hit adds zeros)
+            any_hit = total_sets > 0;    // (a patch whose bins hold entries but no hit adds zeros)
     }
 
     // ---- store the patch once.  Accumulator register r of lane (half, l32) is patch pixel
@@ -1142,19 +1160,19 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
     return owner_ws_header_bytes(B, N) + (size_t)B * Q * P * sizeof(BinEntry);
 }
 
-template <bool ACC>
+template <bool ACC, bool MULTI>
 static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const MsmvArgs &a,
-                               const OwnerWs &ws, const OwnerGeom &geo)
+                               const OwnerSets &sets, const OwnerGeom &geo)
 {
     switch (pt) {
-    case 1: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, ACC>), grid, block, 0, s, a, ws, geo); break;
-    case 2: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, ACC>), grid, block, 0, s, a, ws, geo); break;
-    case 4: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<4, ACC>), grid, block, 0, s, a, ws, geo); break;
-    default: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<0, ACC>), grid, block, 0, s, a, ws, geo); break;
+    case 1: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
+    case 2: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
+    case 4: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<4, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
+    default: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<0, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
     }
 }
 
-hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate)
+static OwnerWs owner_ws_of(const MsmvArgs &a, void *workspace)
 {
     OwnerWs ws;
     ws.keys = a.N * BIN_PER_VIEW;
@@ -1163,6 +1181,72 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     ws.cursors = ws.counts + (size_t)a.B * ws.keys;
     ws.offsets = ws.cursors + (size_t)a.B * ws.keys;
     ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N));
+    return ws;
+}
+
+// The d-feat pass over `sets.n` sorted point sets (each of a.qp points per batch slab).
+static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hipStream_t s, bool accumulate)
+{
+    OwnerGeom geo = {};
+    int per_view = 0;
+    for (int l = 0; l < a.L; ++l) {
+        geo.patch_cols[l] = (a.lvl[l].W + PATCH_W - 1) / PATCH_W;
+        geo.patches[l] = ((a.lvl[l].H + PATCH_H - 1) / PATCH_H) * geo.patch_cols[l];
+        // a point touches ~1.4 patches of a level: expected hits per patch, uniform points
+        const double expect = 1.4 * (double)a.qp * sets.n / ((double)a.N * geo.patches[l]);
+        int klog = 0;
+        while ((2 << klog) <= OWN_WAVES && expect > (double)MSMV_OWN_SPLIT_HITS * (1 << klog))
+            ++klog;
+        geo.split_log2[l] = klog;
+        const int per_wg = OWN_WAVES >> klog;
+        geo.tiles_per_level[l] = (geo.patches[l] + per_wg - 1) / per_wg;
+        geo.div_tiles[l] = msmv_make_div(geo.tiles_per_level[l]);
+        geo.div_cols[l] = msmv_make_div(geo.patch_cols[l]);
+        geo.div_hm1[l] = msmv_make_div(a.lvl[l].H - 1);
+        geo.div_wm1[l] = msmv_make_div(a.lvl[l].W - 1);
+        per_view += geo.tiles_per_level[l];
+    }
+    geo.tiles_per_b = per_view * a.N;
+    geo.div_tiles_per_b = msmv_make_div(geo.tiles_per_b);
+    const long long ntiles = (long long)geo.tiles_per_b * a.B;
+    if (ntiles > 0x7FFFFFFFll)
+        return hipErrorInvalidValue;
+    if (ntiles > 0) {
+        const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
+        const int pt = a.rows ? 1 : a.P;
+        if (sets.n > 1 && accumulate)
+            launch_owner_dfeat<true, true>(pt, grid, block, s, a, sets, geo);
+        else if (sets.n > 1)
+            launch_owner_dfeat<false, true>(pt, grid, block, s, a, sets, geo);
+        else if (accumulate)
+            launch_owner_dfeat<true, false>(pt, grid, block, s, a, sets, geo);
+        else
+            launch_owner_dfeat<false, false>(pt, grid, block, s, a, sets, geo);
+    }
+    return hipGetLastError();
+}
+
+hipError_t msmv_launch_dfeat_sets(const MsmvArgs &a, int nsets, const float *const *gouts,
+                                  void *const *workspaces, hipStream_t s, bool accumulate)
+{
+    if (nsets < 1 || nsets > OWN_MAX_SETS)
+        return hipErrorInvalidValue;
+    OwnerSets sets = {};
+    sets.n = nsets;
+    for (int i = 0; i < nsets; ++i) {
+        const OwnerWs ws = owner_ws_of(a, workspaces[i]);
+        sets.gout[i] = gouts[i];
+        sets.offsets[i] = ws.offsets;
+        sets.entries[i] = ws.entries;
+    }
+    return launch_dfeat_sets(a, sets, s, accumulate);
+}
+
+int msmv_dfeat_max_sets() { return OWN_MAX_SETS; }
+
+hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate)
+{
+    const OwnerWs ws = owner_ws_of(a, workspace);
 
     hipError_t e;
     if ((stages & 1) && a.qp > 0 && a.qp <= BIN_ONE_PPT * BIN_THREADS) {
@@ -1187,38 +1271,13 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     }
 
     if (stages & 2) {
-        OwnerGeom geo = {};
-        int per_view = 0;
-        for (int l = 0; l < a.L; ++l) {
-            geo.patch_cols[l] = (a.lvl[l].W + PATCH_W - 1) / PATCH_W;
-            geo.patches[l] = ((a.lvl[l].H + PATCH_H - 1) / PATCH_H) * geo.patch_cols[l];
-            // a point touches ~1.4 patches of a level: expected hits per patch, uniform points
-            const double expect = 1.4 * (double)a.qp / ((double)a.N * geo.patches[l]);
-            int klog = 0;
-            while ((2 << klog) <= OWN_WAVES && expect > (double)MSMV_OWN_SPLIT_HITS * (1 << klog))
-                ++klog;
-            geo.split_log2[l] = klog;
-            const int per_wg = OWN_WAVES >> klog;
-            geo.tiles_per_level[l] = (geo.patches[l] + per_wg - 1) / per_wg;
-            geo.div_tiles[l] = msmv_make_div(geo.tiles_per_level[l]);
-            geo.div_cols[l] = msmv_make_div(geo.patch_cols[l]);
-            geo.div_hm1[l] = msmv_make_div(a.lvl[l].H - 1);
-            geo.div_wm1[l] = msmv_make_div(a.lvl[l].W - 1);
-            per_view += geo.tiles_per_level[l];
-        }
-        geo.tiles_per_b = per_view * a.N;
-        geo.div_tiles_per_b = msmv_make_div(geo.tiles_per_b);
-        const long long ntiles = (long long)geo.tiles_per_b * a.B;
-        if (ntiles > 0x7FFFFFFFll)
-            return hipErrorInvalidValue;
-        if (ntiles > 0) {
-            const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
-            const int pt = a.rows ? 1 : a.P;
-            if (accumulate)
-                launch_owner_dfeat<true>(pt, grid, block, s, a, ws, geo);
-            else
-                launch_owner_dfeat<false>(pt, grid, block, s, a, ws, geo);
-        }
+        OwnerSets sets = {};
+        sets.n = 1;
+        sets.gout[0] = a.gout;
+        sets.offsets[0] = ws.offsets;
+        sets.entries[0] = ws.entries;
+        if ((e = launch_dfeat_sets(a, sets, s, accumulate)) != hipSuccess)
+            return e;
     }
     if ((e = hipGetLastError()) != hipSuccess)
         return e;

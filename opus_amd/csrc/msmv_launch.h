@@ -29,3 +29,9 @@ hipError_t msmv_launch_project_pack_backward(const float *dloc, const float *dw,
 // Producer-side re-layout (msmv_relayout.hip): [B,T*N,G*C,H,W] <-> [B*T*G,N,H,W,C].
 hipError_t msmv_launch_relayout(const float *src, float *dst, int B, int T, int N, int G, int C, int H, int W,
                                 bool inverse, hipStream_t s);
+
+// One d-feat pass over several point sets sorted by earlier OPUS_MSMV_BWD_STAGE_BIN calls with
+// these sizes (workspaces[i]) and their gradients of the op's output (gouts[i]).
+int msmv_dfeat_max_sets();
+hipError_t msmv_launch_dfeat_sets(const MsmvArgs &a, int nsets, const float *const *gouts,
+                                  void *const *workspaces, hipStream_t s, bool accumulate);

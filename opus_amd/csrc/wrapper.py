@@ -157,7 +157,8 @@ def backward_workspace_bytes(feats, loc, w, flags=0):
 def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None, flags=0, rows=None):
     """Raw backward into caller-owned buffers (no allocation here when ``workspace`` is
     given).  ``flags``: algorithm | ACCUMULATE | STAGE_* bits of include/opus_msmv.h.
-    ``rows=(T, G)``: grad_out is [Bs, Q, G, T*P, C] (see msmv_forward)."""
+    ``rows=(T, G)``: grad_out is [Bs, Q, G, T*P, C] (see msmv_forward).  ``dfeats`` may be None
+    when the stages asked for do not include the d-feat pass."""
     L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
     if rows is None:
         want = (B, Q, C, P)
@@ -167,7 +168,7 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
     if not grad_out.is_contiguous() or tuple(grad_out.shape) != want \
             or grad_out.dtype != torch.float32 or grad_out.device != loc.device:
         raise RuntimeError(f"grad_output must be a contiguous float32 {list(want)} tensor on the inputs' device")
-    for d, f in zip(dfeats, feats):
+    for d, f in zip(dfeats or [], feats):
         if d.shape != f.shape or not d.is_contiguous() or d.dtype != torch.float32 or d.device != f.device:
             raise RuntimeError("d feats must match feats in shape, dtype and device and be contiguous")
     if dloc.shape != loc.shape or dw.shape != w.shape or not dloc.is_contiguous() or not dw.is_contiguous():
@@ -179,7 +180,8 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
             workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=loc.device)
         head = (L, grad_out.data_ptr(), _lib.ptr_array([f.data_ptr() for f in feats]),
                 _lib.int_array(hw), loc.data_ptr(), w.data_ptr())
-        tail = (_lib.ptr_array([d.data_ptr() for d in dfeats]), dloc.data_ptr(), dw.data_ptr(),
+        tail = (_lib.ptr_array([d.data_ptr() for d in dfeats]) if dfeats is not None else None,
+                dloc.data_ptr(), dw.data_ptr(),
                 workspace.data_ptr(), workspace.numel() * workspace.element_size(), flags,
                 _stream_ptr(loc.device))
         if rows is None:
@@ -187,6 +189,37 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
         else:
             rc = lib.opus_msmv_backward_rows(*head, Bs, T, G, C, N, Q, P, *tail)
     _lib.check(rc, "opus_msmv_backward")
+
+
+def msmv_dfeat_multi(grad_outs, workspaces, feats, Q, P, dfeats, rows=None, accumulate=False):
+    """One d-feat pass over several layers' sorted point sets (opus_msmv_dfeat_multi): set i is
+    ``grad_outs[i]`` + the workspace its layer's sort stage filled.  ``feats`` gives the sizes."""
+    lib = _lib.load()
+    L = len(feats)
+    B, N, _, _, C = feats[0].shape
+    hw = [d for f in feats for d in f.shape[2:4]]
+    dev = feats[0].device
+    if rows is None:
+        dims, want = (B, 0, 0), (B, Q, C, P)
+    else:
+        Bs, T, G = _check_rows(B, rows)
+        dims, want = (Bs, T, G), (Bs, Q, G, T * P, C)
+    for g in grad_outs:
+        if not g.is_contiguous() or tuple(g.shape) != want or g.dtype != torch.float32 or g.device != dev:
+            raise RuntimeError(f"grad_output must be a contiguous float32 {list(want)} tensor on the inputs' device")
+    for d, f in zip(dfeats, feats):
+        if d.shape != f.shape or not d.is_contiguous() or d.dtype != torch.float32 or d.device != dev:
+            raise RuntimeError("d feats must match feats in shape, dtype and device and be contiguous")
+    if len(grad_outs) != len(workspaces) or not grad_outs:
+        raise RuntimeError("one workspace per grad_output, at least one")
+    ws_bytes = min(x.numel() * x.element_size() for x in workspaces)
+    with torch.cuda.device(dev):
+        rc = lib.opus_msmv_dfeat_multi(L, len(grad_outs), _lib.ptr_array([g.data_ptr() for g in grad_outs]),
+                                       _lib.ptr_array([x.data_ptr() for x in workspaces]), ws_bytes,
+                                       _lib.int_array(hw), *dims, C, N, Q, P,
+                                       _lib.ptr_array([d.data_ptr() for d in dfeats]),
+                                       _lib.BWD_ACCUMULATE if accumulate else 0, _stream_ptr(dev))
+    _lib.check(rc, "opus_msmv_dfeat_multi")
 
 
 def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None, out_dfeats=None):
@@ -260,7 +293,11 @@ class FeatureGradSink:
     The reference lets each of the 6 layers allocate and zero a fresh 735 MB (per sample)
     gradient and autograd add them (msmv_sampling.cpp:244-247).  With a sink the first
     backward that runs writes the buffers, the following ones accumulate into them
-    (OPUS_MSMV_BWD_ACCUMULATE), and the total is handed to autograd once, after the last one:
+    (OPUS_MSMV_BWD_ACCUMULATE), and the total is handed to autograd once, after the last one.
+    Where the owner algorithm applies (``defer=None`` decides so; True / False force it) the d
+    feats are deferred altogether: a layer's backward only sorts its points and computes its d loc
+    / d weights, keeps its grad_output and sort, and ONE pass after the last layer accumulates
+    all layers' points (opus_msmv_dfeat_multi) - d feats are written once, never read:
 
         sink = FeatureGradSink(mlvl_feats)          # channel-last [B',N,H,W,C] tensors
         for layer in layers:
@@ -271,8 +308,14 @@ class FeatureGradSink:
     the buffers cannot run before all of them have.
     """
 
-    def __init__(self, mlvl_feats):
+    def __init__(self, mlvl_feats, defer=None):
         self.feats = [f.detach() for f in mlvl_feats]
+        if defer is None:
+            B, N, _, _, C = self.feats[0].shape     # non-zero workspace <=> the owner algorithm applies
+            defer = _bwd_algo != "atomic" and \
+                _lib.load().opus_msmv_backward_workspace_bytes(len(self.feats), B, C, N, 1, 1, 0) > 0
+        self.defer = bool(defer)
+        self.pending = []                       # deferred: (grad_output, workspace, Q, P, rows) per layer
         self.buffers = None                     # allocated by the first backward
         self.token = _SinkOpen.apply(self, *mlvl_feats)
 
@@ -289,6 +332,22 @@ class _SinkOpen(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _gtoken):
         sink = ctx.sink
+        if sink.pending:
+            # one pass per group of layers with equal sizes, at most max_sets layers per launch
+            first = sink.buffers is None
+            if first:
+                sink.buffers = [torch.empty_like(f) for f in sink.feats]
+            groups = {}
+            for g, ws, Q, P, rows in sink.pending:
+                groups.setdefault((Q, P, rows), []).append((g, ws))
+            cap = _lib.load().opus_msmv_dfeat_max_sets()
+            for (Q, P, rows), sets in groups.items():
+                for i in range(0, len(sets), cap):
+                    part = sets[i:i + cap]
+                    msmv_dfeat_multi([g for g, _ in part], [ws for _, ws in part], sink.feats, Q, P,
+                                     sink.buffers, rows=rows, accumulate=not first)
+                    first = False
+            sink.pending = []
         grads = sink.buffers if sink.buffers is not None else [None] * len(sink.feats)
         sink.buffers = None                     # a later backward (retain_graph) starts afresh
         return (None, *grads)
@@ -305,6 +364,17 @@ class _MSMVSamplingSink(torch.autograd.Function):
     def backward(ctx, grad_output):
         sink = ctx.sink
         sampling_locations, scale_weights = ctx.saved_tensors
+        if sink.defer:
+            g = grad_output.contiguous()
+            flags = _lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER
+            need = backward_workspace_bytes(sink.feats, sampling_locations, scale_weights, flags)
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=g.device)
+            dloc, dw = torch.empty_like(sampling_locations), torch.empty_like(scale_weights)
+            msmv_backward_into(g, sink.feats, sampling_locations, scale_weights, None, dloc, dw,
+                               workspace=ws, flags=flags, rows=ctx.rows)
+            _, Q, P, _ = sampling_locations.shape
+            sink.pending.append((g, ws, Q, P, ctx.rows))
+            return None, None, grad_output.new_zeros(()), dloc, dw
         first = sink.buffers is None
         if first:
             sink.buffers = [torch.empty_like(f) for f in sink.feats]

@@ -278,8 +278,9 @@ def test_relayout_full_size_round_trip(ops):
 
 
 # ---------------------------------------------------------------- shared d-feat buffers
+@pytest.mark.parametrize("defer", [True, False], ids=["deferred", "accumulated"])
 @pytest.mark.parametrize("rows", [None, (2, 2)], ids=["plain", "rows"])
-def test_feature_grad_sink_equals_autograd_sum(ops, rows):
+def test_feature_grad_sink_equals_autograd_sum(ops, rows, defer):
     """Three layers sampling the same feature maps: one shared, accumulated d-feat buffer must
     give what autograd's sum of three separate gradients gives; d loc / d w per layer too."""
     from opus_amd.csrc import wrapper as wr
@@ -291,7 +292,8 @@ def test_feature_grad_sink_equals_autograd_sum(ops, rows):
     def run(use_sink):
         f = [dev(x).requires_grad_(True) for x in feats]
         lw = [(dev(l).requires_grad_(True), dev(w).requires_grad_(True)) for l, w in layers]
-        src = wr.FeatureGradSink(f) if use_sink else f
+        src = wr.FeatureGradSink(f, defer=defer) if use_sink else f
+        assert not use_sink or src.defer == defer
         total = 0
         gen.manual_seed(9)
         for l, w in lw:
@@ -308,6 +310,94 @@ def test_feature_grad_sink_equals_autograd_sum(ops, rows):
     for (la, wa), (lb, wb) in zip(lw_snk, lw_ref):
         assert_close(la.grad.cpu().numpy(), lb.grad.cpu().numpy(), 1e-5, "dloc")
         assert_close(wa.grad.cpu().numpy(), wb.grad.cpu().numpy(), 1e-5, "dw")
+
+
+@pytest.mark.parametrize("case", [
+    # (levels, B, Q, P, rows, layers): few points on real level sizes; crowded coarse levels whose
+    # patches are shared by several waves; more layers than one launch takes; row mode; no points
+    ("real", 4, 150, 2, None, 3),
+    ("tiny", 2, 900, 4, None, 3),
+    ("real", 4, 40, 1, None, 10),
+    ("real", 4, 60, 2, (2, 2), 4),
+    ("tiny", 2, 33, 3, None, 2),
+    ("real", 4, 0, 2, None, 2),
+], ids=["real-p2", "crowded-p4", "ten-layers-p1", "rows", "p3-generic", "no-points"])
+def test_deferred_dfeat_over_several_layers_matches_oracle_sum(ops, case):
+    """Every layer sorts and gathers on its own (d loc / d w per layer equal the one-call
+    backward's); one opus_msmv_dfeat_multi per batch of layers then writes d feats, started on
+    NaN-filled buffers: equal to the oracle's sum over the layers at the gradient tolerance and to
+    the sum of the one-call backward's d feats at 1e-5."""
+    from opus_amd import _lib
+    from opus_amd.csrc import wrapper as wr
+    from oracle import msmv_oracle
+    levels_name, B, Q, P, rows, nlayers = case
+    levels = REAL_LEVELS if levels_name == "real" else TINY_LEVELS
+    N, C = 6, 64
+    feats, _, _, _ = random_case(600, levels, B, N, C, max(Q, 1), P)
+    f = [dev(x) for x in feats]
+    layers = []
+    for i in range(nlayers):
+        _, loc, w, _ = random_case(601 + i, levels, B, N, 1, Q, P)
+        shape = (B, Q, C, P) if rows is None else (B // (rows[0] * rows[1]), Q, rows[1], rows[0] * P, C)
+        gout = np.random.default_rng(650 + i).standard_normal(shape).astype(np.float32)
+        layers.append((loc, w, gout))
+    flags = _lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER
+    kept, dense = [], [torch.zeros_like(x) for x in f]
+    for loc, w, gout in layers:
+        l, ww, g = dev(loc), dev(w), dev(gout)
+        ws = torch.empty(max(wr.backward_workspace_bytes(f, l, ww, flags), 16), dtype=torch.uint8, device="cuda")
+        dloc, dw = torch.full_like(l, float("nan")), torch.full_like(ww, float("nan"))
+        wr.msmv_backward_into(g, f, l, ww, None, dloc, dw, workspace=ws, flags=flags, rows=rows)
+        one, dl_ref, dw_ref = wr.msmv_backward(g, f, l, ww, algo="owner", rows=rows)
+        if Q:
+            assert_close(dloc.cpu().numpy(), dl_ref.cpu().numpy(), 1e-6, "dloc, sort + gather only")
+            assert_close(dw.cpu().numpy(), dw_ref.cpu().numpy(), 1e-6, "dw, sort + gather only")
+        for d, o in zip(dense, one):
+            d += o
+        kept.append((g, ws))
+    out = [torch.full_like(x, float("nan")) for x in f]
+    cap = _lib.load().opus_msmv_dfeat_max_sets()
+    assert cap == 8
+    for i in range(0, nlayers, cap):
+        part = kept[i:i + cap]
+        wr.msmv_dfeat_multi([g for g, _ in part], [w_ for _, w_ in part], f, Q, P, out, rows=rows,
+                            accumulate=i > 0)
+    torch.cuda.synchronize()
+    ref = [np.zeros_like(x) for x in feats]
+    for loc, w, gout in layers:
+        if rows is not None:            # [Bs,Q,G,T*P,C] -> [Bs*T*G,Q,C,P]
+            T, G = rows
+            gout = gout.reshape(B // (T * G), Q, G, T, P, C).transpose(0, 3, 2, 1, 5, 4).reshape(B, Q, C, P)
+        if Q:
+            df, _, _ = msmv_oracle.backward(np.ascontiguousarray(gout), feats, loc, w)
+            for r, d in zip(ref, df):
+                r += d
+    for i, (a, d, r) in enumerate(zip(out, dense, ref)):
+        assert not torch.isnan(a).any(), f"level {i}: elements left unwritten"
+        assert_close(a.cpu().numpy(), d.cpu().numpy(), 1e-5, f"dfeat{i}, deferred against per-layer sum",
+                     atol_floor=1e-30)
+        assert_close(a.cpu().numpy(), r, GRAD_RTOL, f"dfeat{i}, deferred against the oracle", atol_floor=1e-30)
+
+
+def test_deferred_dfeat_rejects_bad_arguments(ops):
+    from opus_amd.csrc import wrapper as wr
+    B, N, Q, P = 2, 6, 8, 2
+    feats, loc, w, gout = random_case(690, TINY_LEVELS, B, N, 64, Q, P)
+    f = [dev(x) for x in feats]
+    g = dev(gout)
+    ws = torch.empty(max(wr.backward_workspace_bytes(f, dev(loc), dev(w), 2), 16), dtype=torch.uint8, device="cuda")
+    d = [torch.empty_like(x) for x in f]
+    with pytest.raises(RuntimeError, match="dimensions"):
+        wr.msmv_dfeat_multi([g] * 9, [ws] * 9, f, Q, P, d)                 # more sets than one launch takes
+    with pytest.raises(RuntimeError, match="workspace"):
+        wr.msmv_dfeat_multi([g], [ws[:64]], f, Q, P, d)
+    with pytest.raises(RuntimeError, match="grad_output"):
+        wr.msmv_dfeat_multi([g[:1]], [ws], f, Q, P, d)
+    feats32 = [dev(x[..., :32].copy()) for x in feats]                     # C = 32: no owner algorithm
+    with pytest.raises(RuntimeError, match="flag"):
+        wr.msmv_dfeat_multi([g[:, :, :32].contiguous()], [ws], feats32, Q, P, [torch.empty_like(x) for x in feats32])
+    assert not wr.FeatureGradSink([x.requires_grad_(True) for x in feats32]).defer
+    assert wr.FeatureGradSink([x.requires_grad_(True) for x in f]).defer
 
 
 def test_feature_grad_sink_through_relayout_and_sampling_4d(ops):

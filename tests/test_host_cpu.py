@@ -86,6 +86,21 @@ def test_argument_validation_returns_before_any_launch(lib):
     assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 2, null, null, null) == -7   # unknown flag
     assert pp(null, null, null, 1, 0, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 0, null, null, null) == 0
     assert n >= 32 * 4800 * 2 * 32 and n < 32 * 4800 * 2 * 32 + (1 << 20)
+    # sort / gather stages alone need no d feats; the deferred d-feat pass validates its sets
+    assert bwd(1, null, ptrs, hw, null, null, 1, 64, 6, 1, 1, None, null, null, null, 0, 0x502, null) == -4
+    assert bwd(1, null, ptrs, hw, null, null, 1, 64, 6, 1, 1, None, null, null, null, 0, 0x202, null) == -4
+    assert bwd(1, null, ptrs, hw, null, null, 0, 64, 6, 1, 1, None, null, null, null, 0, 0x502, null) == 0
+    multi = lib.opus_msmv_dfeat_multi
+    assert lib.opus_msmv_dfeat_max_sets() == 8
+    real = _lib.int_array([64, 176, 32, 88, 16, 44, 8, 22])
+    p4 = _lib.ptr_array([0, 0, 0, 0])
+    assert multi(4, 0, ptrs, ptrs, 0, real, 32, 0, 0, 64, 6, 10, 2, p4, 0, null) == -3      # no sets
+    assert multi(4, 9, ptrs, ptrs, 0, real, 32, 0, 0, 64, 6, 10, 2, p4, 0, null) == -3      # too many
+    assert multi(4, 1, ptrs, ptrs, 0, real, 32, 0, 0, 32, 6, 10, 2, p4, 0, null) == -7      # C != 64
+    assert multi(4, 1, ptrs, ptrs, 0, real, 32, 0, 0, 64, 6, 10, 2, p4, 1, null) == -7      # unknown flag
+    assert multi(4, 1, ptrs, ptrs, 0, real, 32, 0, 0, 64, 6, 10, 2, p4, 0, null) == -4      # null d feats
+    assert multi(4, 1, ptrs, ptrs, 0, real, 4, 8, 0, 64, 6, 10, 2, p4, 0, null) == -3       # rows: G < 1
+    assert multi(4, 1, ptrs, ptrs, 0, real, 0, 0, 0, 64, 6, 10, 2, p4, 0, null) == 0        # empty batch
 
 
 def test_wrapper_mirrors_reference_names_and_checks():
