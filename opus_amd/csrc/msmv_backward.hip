@@ -550,8 +550,11 @@ struct OwnHit {
 // ACC: add the patch to what d feat already holds instead of overwriting it (one decoder
 // layer after another accumulating into one buffer); a patch that no point reaches is then
 // left alone.
-// MULTI: more than one point set (the loop over sets costs registers, hence occupancy: the
-// single-set kernel is compiled without it).
+// MULTI: more than one point set.  The segments of all sets (one per set and y-band, at most
+// OWN_MAX_SETS * BIN_YB = 64: one per lane) are then walked as ONE concatenation, so that a
+// patch still costs one chain of dependent loads (offsets -> entries -> gradient rows) and not
+// one per set; a hit record carries its set, which selects the gradient array.  The tables
+// this needs cost registers, hence occupancy: the single-set kernel is compiled without them.
 template <int PT, bool ACC, bool MULTI>
 __global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(MSMV_OWN_OCC)))
 msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
@@ -579,6 +582,25 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *queue = queue_all[wave];
     [[maybe_unused]] float4 *stage = stage_all[wave];
+    // MULTI: the sets' gradient arrays, and per wave the concatenation's segment table
+    // (entries before the segment, address of its first entry)
+    __shared__ const float *gout_tab[MULTI ? OWN_MAX_SETS : 1];
+    __shared__ int excl_tab_all[MULTI ? OWN_WAVES : 1][64];
+    __shared__ unsigned long long addr_tab_all[MULTI ? OWN_WAVES : 1][64];
+    [[maybe_unused]] int *excl_tab = excl_tab_all[MULTI ? wave : 0];
+    [[maybe_unused]] unsigned long long *addr_tab = addr_tab_all[MULTI ? wave : 0];
+    if constexpr (MULTI) {
+        static_assert(OWN_MAX_SETS * BIN_YB <= 64, "one lane per (set, y-band) segment");
+        if (threadIdx.x < OWN_MAX_SETS) {
+            // static indices only: a lane-indexed read would copy the argument block to scratch
+            const float *g = sets.gout[0];
+#pragma unroll
+            for (int i = 1; i < OWN_MAX_SETS; ++i)
+                g = (int)threadIdx.x == i ? sets.gout[i] : g;
+            gout_tab[threadIdx.x] = g;
+        }
+        __syncthreads();
+    }
 
     // ---- which patch: logical order [b][level, coarse first][view][tile][wave / K]
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
@@ -616,16 +638,33 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
     msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, geo.div_wm1[l], xb_lo, xb_hi);
     const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
     const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB
-    int total_sets = 0;                                      // entries of the patch's bins over all sets
-    for (int set = 0; set < (MULTI ? sets.n : 1); ++set) {
-    const float *gout = sets.gout[set];
-    const int *off = sets.offsets[set] + (size_t)b * (a.N * BIN_PER_VIEW + 1) + view * BIN_PER_VIEW;
-    const float4 *list = reinterpret_cast<const float4 *>(sets.entries[set] + (size_t)b * a.qp);
+    [[maybe_unused]] const float *gout = sets.gout[0];
+    const size_t off_slab = (size_t)b * (a.N * BIN_PER_VIEW + 1) + view * BIN_PER_VIEW;
+    [[maybe_unused]] const float4 *list = reinterpret_cast<const float4 *>(sets.entries[0] + (size_t)b * a.qp);
 
-    // Lane s holds segment s: its length, the count of entries before it (excl) and
-    // delta = begin - excl, so that virtual entry v of the concatenation is list[v + delta].
+    // Lane s holds segment s (MULTI: segment s % BIN_YB of set s / BIN_YB): its length, the
+    // count of entries before it (excl) and delta = begin - excl, so that virtual entry v of
+    // the concatenation is list[v + delta] (MULTI: the address of its first entry instead).
     int seg_len = 0, seg_begin = 0;
-    if (lane < nseg) {
+    [[maybe_unused]] unsigned long long seg_addr = 0;
+    if constexpr (MULTI) {
+        const int sset = lane / BIN_YB, sseg = lane % BIN_YB;
+        if (sset < sets.n && sseg < nseg) {
+            const int *offp = sets.offsets[0];
+            const BinEntry *entp = sets.entries[0];
+#pragma unroll
+            for (int i = 1; i < OWN_MAX_SETS; ++i) {
+                offp = sset == i ? sets.offsets[i] : offp;
+                entp = sset == i ? sets.entries[i] : entp;
+            }
+            const int k_lo = all_x ? yb_lo * BIN_XB : (yb_lo + sseg) * BIN_XB + xb_lo;
+            const int k_hi = all_x ? (yb_hi + 1) * BIN_XB : (yb_lo + sseg) * BIN_XB + xb_hi + 1;
+            seg_begin = offp[off_slab + k_lo];
+            seg_len = offp[off_slab + k_hi] - seg_begin;
+            seg_addr = reinterpret_cast<unsigned long long>(entp + (size_t)b * a.qp + seg_begin);
+        }
+    } else if (lane < nseg) {
+        const int *off = sets.offsets[0] + off_slab;
         const int k_lo = all_x ? yb_lo * BIN_XB : (yb_lo + lane) * BIN_XB + xb_lo;
         const int k_hi = all_x ? (yb_hi + 1) * BIN_XB : (yb_lo + lane) * BIN_XB + xb_hi + 1;
         seg_begin = off[k_lo];
@@ -633,32 +672,55 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
     }
     int incl = seg_len;
 #pragma unroll
-    for (int d = 1; d < BIN_YB; d <<= 1) {
+    for (int d = 1; d < (MULTI ? 64 : BIN_YB); d <<= 1) {
         const int up = __shfl_up(incl, d);
         if (lane >= d)
             incl += up;
     }
     const int seg_excl = incl - seg_len;
-    const int seg_delta = seg_begin - seg_excl;
-    const int total = idle ? 0 : __builtin_amdgcn_readlane(incl, nseg - 1);
+    [[maybe_unused]] const int seg_delta = seg_begin - seg_excl;
+    const int total = idle ? 0 : __builtin_amdgcn_readlane(incl, MULTI ? 63 : nseg - 1);
+    if constexpr (MULTI) {
+        excl_tab[lane] = seg_excl;          // non-decreasing; lanes past the last segment hold `total`
+        addr_tab[lane] = seg_addr;
+    }
 
     // This wave's j-th entry is virtual entry j*K + sub of the concatenated segments.
     // entry_index: its index in the entry array for j = j0 + lane (clamped into range so that
     // every lane loads something).
     auto entry_index = [&](int j0) {
         const int v = min(((j0 + lane) << klog) + sub, total - 1);
-        int idx = v + __builtin_amdgcn_readlane(seg_delta, 0);
-        for (int sgm = 1; sgm < nseg; ++sgm) {
-            const int cs = __builtin_amdgcn_readlane(seg_excl, sgm);
-            const int ds = __builtin_amdgcn_readlane(seg_delta, sgm);
-            idx = v >= cs ? v + ds : idx;
+        if constexpr (MULTI) {
+            // the last segment that begins at or before v (empty segments share their successor's
+            // count and are skipped by that rule): six probes of the wave's table
+            int g = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1)
+                g = excl_tab[g + step] <= v ? g + step : g;
+            return ((long long)g << 32) | (unsigned)(v - excl_tab[g]);   // segment, entry within it
+        } else {
+            int idx = v + __builtin_amdgcn_readlane(seg_delta, 0);
+            for (int sgm = 1; sgm < nseg; ++sgm) {
+                const int cs = __builtin_amdgcn_readlane(seg_excl, sgm);
+                const int ds = __builtin_amdgcn_readlane(seg_delta, sgm);
+                idx = v >= cs ? v + ds : idx;
+            }
+            return idx;
         }
-        return idx;
     };
-    // weight l of an entry sits in dword 3 + l
-    auto load_entry = [&](int idx, float4 &e0, float &wl) {
-        e0 = list[(size_t)idx * 2];
-        wl = reinterpret_cast<const float *>(list + (size_t)idx * 2)[3 + l];
+    // weight l of an entry sits in dword 3 + l; eset: the set the entry belongs to (MULTI)
+    auto load_entry = [&](auto ref, float4 &e0, float &wl, int &eset) {
+        if constexpr (MULTI) {
+            const int g = (int)(ref >> 32);
+            const unsigned within = (unsigned)ref;
+            const float4 *e = reinterpret_cast<const float4 *>(addr_tab[g] + (unsigned long long)within * sizeof(BinEntry));
+            e0 = e[0];
+            wl = reinterpret_cast<const float *>(e)[3 + l];
+            eset = g / BIN_YB;
+        } else {
+            e0 = list[(size_t)ref * 2];
+            wl = reinterpret_cast<const float *>(list + (size_t)ref * 2)[3 + l];
+        }
     };
     auto scan = [&](int j0, const float4 &e0, float wl) {
         OwnHit h;
@@ -690,11 +752,13 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
     if (sub < total) {
         float4 e0;
         float wl;
-        load_entry(entry_index(0), e0, wl);
+        [[maybe_unused]] int eset = 0;
+        load_entry(entry_index(0), e0, wl, eset);
         for (int j0 = 0; (j0 << klog) + sub < total; j0 += 64) {
             const OwnHit h = scan(j0, e0, wl);
+            [[maybe_unused]] const float hset = __int_as_float(eset);   // rides in the record's spare slot
             if (((j0 + 64) << klog) + sub < total)             // next chunk's entries, in flight
-                load_entry(entry_index(j0 + 64), e0, wl);      // while this chunk's hits are applied
+                load_entry(entry_index(j0 + 64), e0, wl, eset);     // while this chunk's hits are applied
 
             unsigned long long hits = __ballot(h.hit);
 #ifdef MSMV_ABL_NOHITS
@@ -712,12 +776,12 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
                 // can then be consumed in whole groups without branches around the loads
                 if (lane < QC) {
                     queue[lane * 2] = make_float4(__int_as_float(h.pt), 0.f, 0.f, 0.f);
-                    queue[lane * 2 + 1] = make_float4(0.f, __uint_as_float(0xFFFFFFFFu), 0.f, 0.f);
+                    queue[lane * 2 + 1] = make_float4(0.f, __uint_as_float(0xFFFFFFFFu), MULTI ? hset : 0.f, 0.f);
                 }
                 const unsigned slot = (unsigned)(rank - qbase);
                 if (h.hit && slot < (unsigned)QC) {
                     queue[slot * 2] = make_float4(__int_as_float(h.pt), h.cw1, h.cw2, h.cw3);
-                    queue[slot * 2 + 1] = make_float4(h.cw4, __uint_as_float(h.pix), 0.f, 0.f);
+                    queue[slot * 2 + 1] = make_float4(h.cw4, __uint_as_float(h.pix), MULTI ? hset : 0.f, 0.f);
                 }
                 const int cnt = min(QC, nh - qbase);
 
@@ -743,14 +807,19 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
                     const int ninstr = (cnt + RPI - 1) / RPI;
                     const float *qf = reinterpret_cast<const float *>(queue);
                     int rpt[MAXI];
+                    const float *rgo[MAXI];
 #pragma unroll
-                    for (int i = 0; i < MAXI; ++i)                     // the record this lane copies a piece of
+                    for (int i = 0; i < MAXI; ++i) {                   // the record this lane copies a piece of
                         rpt[i] = __float_as_int(qf[(i * RPI + lane / ROW_F4) * 8]);
+                        rgo[i] = gout;
+                        if constexpr (MULTI)
+                            rgo[i] = gout_tab[__float_as_int(qf[(i * RPI + lane / ROW_F4) * 8 + 6])];
+                    }
 #pragma unroll
                     for (int i = 0; i < MAXI; ++i) {
                         if (i < ninstr) {                              // wave-uniform
                             const int row = PT == 4 ? rpt[i] >> 2 : PT == 2 ? rpt[i] >> 1 : rpt[i];
-                            const float *src = gout + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
+                            const float *src = rgo[i] + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
                             __builtin_amdgcn_global_load_lds((msmv_gptr_t)src, (msmv_lptr_t)(stage + i * 64), 16, 0, 0);
                         }
                     }
@@ -795,7 +864,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
                 _Pragma("unroll") for (int u = 0; u < GP; ++u) {                             \
                     const float *q = reinterpret_cast<const float *>(queue + (((G) * GP + u) * 2 + half) * 2); \
                     X##_pt[u] = __float_as_int(q[0]);                                         \
-                    X##_g[u] = msmv_load_grad<PT>(a, gout, X##_pt[u], l32);                  \
+                    X##_g[u] = msmv_load_grad<PT>(a, MULTI ? gout_tab[__float_as_int(q[6])] : gout, X##_pt[u], l32); \
                 }
 #define MSMV_OWN_APPLY(X, G)                                                                  \
                 _Pragma("unroll") for (int u = 0; u < GP; ++u) {                             \
@@ -834,8 +903,6 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
             }
         }
     }
-    total_sets += total;
-    }   // sets
 
     // ---- K > 1: sum the K partial tiles of a patch, halving the live waves per round.  The
     // round count is the workgroup's (one level, one K): every wave reaches every barrier.
@@ -866,7 +933,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
         return;
     if constexpr (ACC) {
         if (K > 1)
-            any_hit = total_sets > 0;    // (a patch whose bins hold entries but no hit adds zeros)
+            any_hit = total > 0;         // (a patch whose bins hold entries but no hit adds zeros)
     }
 
     // ---- store the patch once.  Accumulator register r of lane (half, l32) is patch pixel
