@@ -105,6 +105,19 @@ def main():
     res["sampling_4d_fwdbwd_us_fused_expanded_views"] = timed(chain_expanded, max(args.iters // 2, 5))
     res["sampling_4d_fwdbwd_us_fused_shared_frames"] = timed(chain_shared, max(args.iters // 2, 5))
 
+    # a stack of six layers sampling the same feature maps, forward + backward through autograd:
+    # six separate 735 MB d feats summed by autograd, one buffer the layers accumulate into, and
+    # d feats deferred to one pass over all six layers' points
+    def stack(kind):
+        bp.grad = bs.grad = None
+        for f in feats:
+            f.grad = None
+        src = feats if kind == "autograd" else wrapper.FeatureGradSink(feats, defer=kind == "deferred")
+        outs = [opus_sampling.sampling_4d(bp, src, bs, occ2img, H, W, N, num_frames=T) for _ in range(6)]
+        torch.autograd.backward(outs, [gout] * 6)
+    for kind in ("autograd", "accumulate", "deferred"):
+        res[f"six_layers_fwdbwd_us_{kind}"] = timed(lambda: stack(kind), max(args.iters // 5, 5), warmup=2)
+
     # the op alone, in its own output layout + the caller's permute copy, against row mode
     with torch.no_grad():
         loc, w = opus_sampling.project_and_pack(pts, sw, occ2img, H, W, N)

@@ -21,6 +21,9 @@ run L_batch8 --batch 8 --steps 20 --no-cpu-baseline
 run L_atomic --bwd-algo atomic --steps 20 --no-cpu-baseline
 run L_cameras --points cameras --no-cpu-baseline
 run decoder-L --workload decoder-L --steps 20 --no-cpu-baseline
+run decoder-L_accumulate --workload decoder-L --dfeat accumulate --steps 20 --no-cpu-baseline
+run decoder-T --workload decoder-T --steps 20 --no-cpu-baseline
+run decoder-T_accumulate --workload decoder-T --dfeat accumulate --steps 20 --no-cpu-baseline
 run sampling4d-L --workload sampling4d-L --no-cpu-baseline
 run sampling4d-T --workload sampling4d-T --no-cpu-baseline
 run L_graph --graph --no-cpu-baseline
