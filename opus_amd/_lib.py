@@ -76,6 +76,11 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C opus_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+        # torch first: it loads the HIP runtime bundled in its wheel by path.  Were this library
+        # loaded before it, the system's copy of libamdhip64 would come in with it, torch would
+        # add its own, and kernels registered with one runtime would be launched on streams of the
+        # other ("HIP kernel launch failed").  With torch's copy resident, the soname resolves to it.
+        import torch  # noqa: F401
         try:
             lib = ctypes.CDLL(LIB_PATH)
         except OSError as e:            # missing libamdhip64 etc.
