@@ -298,7 +298,10 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 // sort of a slab in ONE workgroup and one launch - histogram, scan and placement in LDS, no
 // global counters, nothing to clear beforehand.  Three launches' worth of latency is most of
 // the two-pass sort's time at these sizes.
-constexpr int BIN_ONE_PPT = 3;
+#ifndef MSMV_BIN_ONE_PPT
+#define MSMV_BIN_ONE_PPT 3        // 10 (slabs up to 10240 points in one workgroup) measured 49 vs 26 us at OPUS-L
+#endif
+constexpr int BIN_ONE_PPT = MSMV_BIN_ONE_PPT;
 __global__ void __launch_bounds__(BIN_THREADS)
 msmv_bin_one(const MsmvArgs a, OwnerWs ws)
 {
