@@ -198,6 +198,44 @@ __device__ __forceinline__ int msmv_bin_key(const float *lp, int N)
     return view < 0 ? -1 : (view * BIN_YB + msmv_band_of<BIN_YB>(lp[1])) * BIN_XB + msmv_band_of<BIN_XB>(lp[0]);
 }
 
+// In-place inclusive prefix sum of v[0..keys) (keys <= BIN_MAX_KEYS) by a workgroup of
+// BIN_THREADS threads: a serial run of 4 keys per thread, a shuffle scan across the wave, the 16
+// wave totals through LDS - two barriers (a Hillis-Steele scan over the keys took 22).  Ends
+// with a barrier; v must be complete (and a barrier passed) on entry.
+__device__ __forceinline__ void msmv_block_scan(int *v, int keys, int *wave_tot)
+{
+    constexpr int PER = BIN_MAX_KEYS / BIN_THREADS;
+    static_assert(PER * BIN_THREADS == BIN_MAX_KEYS && BIN_THREADS % 64 == 0, "every key has a thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int x[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = tid * PER + i;
+        sum += k < keys ? v[k] : 0;
+        x[i] = sum;
+    }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += up;
+    }
+    if (lane == 63)
+        wave_tot[wave] = inc;
+    __syncthreads();
+    int before = inc - sum;                       // keys of earlier threads of this wave
+    for (int w = 0; w < wave; ++w)
+        before += wave_tot[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = tid * PER + i;
+        if (k < keys)
+            v[k] = before + x[i];
+    }
+    __syncthreads();
+}
+
 // Counting sort of the points of every batch slab by key, in two short launches with one
 // point per thread and BIN_THREADS points per workgroup.
 // Pass 1: per-workgroup LDS histogram, then one global add per non-empty key.
@@ -228,7 +266,8 @@ __global__ void __launch_bounds__(BIN_THREADS)
 msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 {
     __shared__ int hist[BIN_MAX_KEYS];        // local counts, then the claimed base per key
-    __shared__ int scan[2][BIN_MAX_KEYS];
+    __shared__ int incl[BIN_MAX_KEYS];        // the slab's counts, then their inclusive prefix
+    __shared__ int wave_tot[BIN_THREADS / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / ws.chunks, chunk = blockIdx.x % ws.chunks;
     const int i = chunk * BIN_THREADS + tid;
@@ -237,7 +276,7 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 
     for (int k = tid; k < keys; k += BIN_THREADS) {
         hist[k] = 0;
-        scan[0][k] = ws.counts[(size_t)b * keys + k];
+        incl[k] = ws.counts[(size_t)b * keys + k];
     }
     __syncthreads();
     int key = -1, rank = 0;
@@ -250,24 +289,16 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
         if (key >= 0)
             rank = atomicAdd(&hist[key], 1);
     }
-    // inclusive Hillis-Steele scan of the slab's counts (keys <= 2048: at most 11 steps)
-    int cur = 0;
-    for (int d = 1; d < keys; d <<= 1) {
-        __syncthreads();
-        for (int k = tid; k < keys; k += BIN_THREADS)
-            scan[cur ^ 1][k] = scan[cur][k] + (k >= d ? scan[cur][k - d] : 0);
-        cur ^= 1;
-    }
-    __syncthreads();
+    msmv_block_scan(incl, keys, wave_tot);    // (its first barrier also orders the LDS atomics above)
     for (int k = tid; k < keys; k += BIN_THREADS) {
         const int n = hist[k];
-        const int excl = scan[cur][k] - ws.counts[(size_t)b * keys + k];
+        const int excl = incl[k] - ws.counts[(size_t)b * keys + k];
         hist[k] = excl + (n ? atomicAdd(ws.cursors + (size_t)b * keys + k, n) : 0);
         if (chunk == 0) {
             int *off = ws.offsets + (size_t)b * (keys + 1);
             off[k] = excl;
             if (k == keys - 1)
-                off[keys] = scan[cur][k];
+                off[keys] = incl[k];
         }
     }
     __syncthreads();
@@ -306,7 +337,8 @@ __global__ void __launch_bounds__(BIN_THREADS)
 msmv_bin_one(const MsmvArgs a, OwnerWs ws)
 {
     __shared__ int hist[BIN_MAX_KEYS];
-    __shared__ int scan[2][BIN_MAX_KEYS];
+    __shared__ int incl[BIN_MAX_KEYS];
+    __shared__ int wave_tot[BIN_THREADS / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int keys = ws.keys;
@@ -332,23 +364,16 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
     }
     __syncthreads();
     for (int k = tid; k < keys; k += BIN_THREADS)
-        scan[0][k] = hist[k];
-    int cur = 0;
-    for (int d = 1; d < keys; d <<= 1) {                       // inclusive Hillis-Steele scan
-        __syncthreads();
-        for (int k = tid; k < keys; k += BIN_THREADS)
-            scan[cur ^ 1][k] = scan[cur][k] + (k >= d ? scan[cur][k - d] : 0);
-        cur ^= 1;
-    }
+        incl[k] = hist[k];
     __syncthreads();
+    msmv_block_scan(incl, keys, wave_tot);
     int *off = ws.offsets + (size_t)b * (keys + 1);
     for (int k = tid; k < keys; k += BIN_THREADS) {
-        const int excl = scan[cur][k] - hist[k];
+        const int excl = incl[k] - hist[k];
         off[k] = excl;
         if (k == keys - 1)
-            off[keys] = scan[cur][k];
+            off[keys] = incl[k];
     }
-    __syncthreads();
 #pragma unroll
     for (int u = 0; u < BIN_ONE_PPT; ++u) {
         const int i = u * BIN_THREADS + tid;
@@ -368,7 +393,7 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
                 wv[k] = k < a.L ? wp[k] : 0.f;
             if (a.L <= 4)
                 wv[4] = __int_as_float(key[u] / BIN_PER_VIEW);     // the view, for the gather pass
-            const int pos = scan[cur][key[u]] - hist[key[u]] + rank[u];
+            const int pos = incl[key[u]] - hist[key[u]] + rank[u];
             float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + pos);
             const int id = a.rows ? msmv_row_of((int)pt, a) : (int)pt;
             e[0] = make_float4(__int_as_float(id), x[u], y[u], wv[0]);
