@@ -379,6 +379,46 @@ def test_deferred_dfeat_over_several_layers_matches_oracle_sum(ops, case):
         assert_close(a.cpu().numpy(), r, GRAD_RTOL, f"dfeat{i}, deferred against the oracle", atol_floor=1e-30)
 
 
+def test_deferred_dfeat_randomised_shapes(ops):
+    """Twenty seeded random configurations of the multi-set pass (4 / 5 levels of random sizes,
+    up to 16 views, 1-8 sets, any P, plain and row layout) against the oracle's sum."""
+    from opus_amd import _lib, opus_sampling
+    from opus_amd.csrc import wrapper as wr
+    from oracle import msmv_oracle
+    rng = np.random.default_rng(77)
+    flags = _lib.BWD_OWNER | _lib.BWD_STAGE_BIN
+    for case in range(20):
+        L = int(rng.choice([4, 5]))
+        levels = [(int(rng.integers(1, 41)), int(rng.integers(1, 41))) for _ in range(L)]
+        B, N = int(rng.integers(1, 7)), int(rng.integers(1, 17))
+        Q, P = int(rng.integers(1, 400)), int(rng.choice([1, 2, 3, 4, 8]))
+        nsets = int(rng.integers(1, 9))
+        rows = (B, 1) if case % 2 else None
+        what = f"case {case}: levels {levels} B{B} N{N} Q{Q} P{P} sets {nsets} rows {rows}"
+        feats, _, _, _ = random_case(7000 + case, levels, B, N, 64, 1, P)
+        f = [dev(x) for x in feats]
+        ref = [np.zeros_like(x) for x in feats]
+        gs, wss = [], []
+        for i in range(nsets):
+            _, loc, w, gout = random_case(7100 + 10 * case + i, levels, B, N, 64, Q, P,
+                                          oob_frac=float(rng.choice([0.0, 0.3, 0.8])))
+            df, _, _ = msmv_oracle.backward(gout, feats, loc, w)
+            for r, d in zip(ref, df):
+                r += d
+            l, ww, g = dev(loc), dev(w), dev(gout)
+            if rows is not None:
+                g = opus_sampling.unpack(g, 1, *rows).contiguous()
+            ws = torch.empty(max(wr.backward_workspace_bytes(f, l, ww, flags), 16), dtype=torch.uint8, device="cuda")
+            wr.msmv_backward_into(g, f, l, ww, None, torch.empty_like(l), torch.empty_like(ww), workspace=ws,
+                                  flags=flags, rows=rows)
+            gs.append(g)
+            wss.append(ws)
+        out = [torch.full_like(x, float("nan")) for x in f]
+        wr.msmv_dfeat_multi(gs, wss, f, Q, P, out, rows=rows)
+        for i, (a, r) in enumerate(zip(out, ref)):
+            assert_close(a.cpu().numpy(), r, GRAD_RTOL, f"{what}: dfeat{i}", atol_floor=1e-30)
+
+
 def test_deferred_dfeat_rejects_bad_arguments(ops):
     from opus_amd.csrc import wrapper as wr
     B, N, Q, P = 2, 6, 8, 2
