@@ -445,6 +445,9 @@ constexpr int OWN_THREADS = OWN_WAVES * 64;
 #ifndef MSMV_OWN_SPLIT_HITS
 #define MSMV_OWN_SPLIT_HITS 64                   // expected hits per wave above which a level's patches are shared
 #endif
+#ifndef MSMV_OWN_SPLIT_HITS_MULTI
+#define MSMV_OWN_SPLIT_HITS_MULTI 256            // the same for a pass over several point sets: per-patch set-up is spread over
+#endif                                           // more hits there (six OPUS-L layers: 64 -> 795 us, 256 -> 764, 1024 -> 768 but 1017 on crowded images)
 constexpr int OWN_QCAP = 16;             // hit records a wave queues before consuming them
 constexpr int OWN_GROUP = 2;             // record pairs per group; two groups' gradient loads are in flight
 
@@ -1290,7 +1293,8 @@ static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hi
         // a point touches ~1.4 patches of a level: expected hits per patch, uniform points
         const double expect = 1.4 * (double)a.qp * sets.n / ((double)a.N * geo.patches[l]);
         int klog = 0;
-        while ((2 << klog) <= OWN_WAVES && expect > (double)MSMV_OWN_SPLIT_HITS * (1 << klog))
+        const double split_hits = sets.n > 1 ? MSMV_OWN_SPLIT_HITS_MULTI : MSMV_OWN_SPLIT_HITS;
+        while ((2 << klog) <= OWN_WAVES && expect > split_hits * (1 << klog))
             ++klog;
         geo.split_log2[l] = klog;
         const int per_wg = OWN_WAVES >> klog;
