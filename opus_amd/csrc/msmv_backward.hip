@@ -835,7 +835,10 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
                     // ---- all rows of the round: global -> LDS, 1 KiB per wave instruction
                     constexpr int RPI = 64 / ROW_F4;                   // records per instruction
                     constexpr int MAXI = QC / RPI;
-                    const int ninstr = (cnt + RPI - 1) / RPI;
+                    // records are applied in pairs: with an odd count the last pair's second record
+                    // is a null record (weights 0), and its row must be loaded too - 0 times
+                    // whatever an earlier kernel left in LDS can be NaN
+                    const int ninstr = (cnt + (cnt & 1) + RPI - 1) / RPI;
                     const float *qf = reinterpret_cast<const float *>(queue);
                     int rpt[MAXI];
                     const float *rgo[MAXI];

@@ -167,6 +167,29 @@ def test_many_views_and_max_points(wr, oracle):
         run_hip(wr, feats, loc, w, grad_out, algo="owner")
 
 
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_backward_ignores_what_earlier_kernels_left_in_lds(wr, oracle, P):
+    """LDS is not cleared between kernels.  The d-feat kernel pads its hit queue with null
+    records (weights 0): the gradient rows they point to must be loaded like the others, or
+    0 x stale LDS contents (NaN here: a tiled transpose of a NaN tensor runs first, on every CU)
+    ends up in d feat.  Odd hit counts per round are the case that matters."""
+    from opus_amd import opus_sampling
+    B, N, C, Q = 2, 6, 64, 37
+    feats, loc, w, grad_out = random_case(4200 + P, REAL_LEVELS, B, N, C, Q, P, oob_frac=0.1)
+    f = [dev(x) for x in feats]
+    l, ww, g = dev(loc), dev(w), dev(grad_out)
+    ref = oracle.backward(grad_out, feats, loc, w)
+    poison = torch.full((1, 8 * 6, 4 * 64, 64, 176), float("nan"), device="cuda")
+    for _ in range(3):
+        opus_sampling.relayout_features([poison], 8, 6, 4)
+        dfeats, dloc, dw = wr.msmv_backward(g, f, l, ww, algo="owner")
+        torch.cuda.synchronize()
+        for i, (a, r) in enumerate(zip(dfeats, ref[0])):
+            assert_close(a.cpu().numpy(), r, GRAD_RTOL, f"dfeat{i} after an LDS-poisoning kernel, P={P}")
+        assert_close(dloc.cpu().numpy()[..., :2], ref[1][..., :2], GRAD_RTOL, "dloc")
+        assert_close(dw.cpu().numpy(), ref[2], GRAD_RTOL, "dw")
+
+
 def test_out_of_range_view_and_nan_location(wr, oracle):
     feats, loc, w, grad_out = random_case(5, REAL_LEVELS, B=1, N=6, C=64, Q=8, P=2, oob_frac=0)
     loc[0, 0, 0, 2] = 1.3
