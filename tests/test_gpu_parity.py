@@ -190,6 +190,31 @@ def test_backward_ignores_what_earlier_kernels_left_in_lds(wr, oracle, P):
         assert_close(dw.cpu().numpy(), ref[2], GRAD_RTOL, "dw")
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_backward_overwrites_poisoned_buffers(wr, oracle, algo, P):
+    """Outputs pre-filled with NaN and a workspace pre-filled with 0xFF bytes: the backward's
+    contract is that it ignores what they hold on entry and writes every output element."""
+    from opus_amd import _lib
+    levels = REAL_LEVELS + [(4, 11)]
+    B, N, C, Q = 3, 5, 64, 90
+    feats, loc, w, grad_out = random_case(4300 + P, levels, B, N, C, Q, P, oob_frac=0.5)
+    loc[0, :5, :, 2] = 7.0                        # some points without a valid view
+    f = [dev(x) for x in feats]
+    l, ww, g = dev(loc), dev(w), dev(grad_out)
+    flags = _lib.BWD_OWNER if algo == "owner" else _lib.BWD_ATOMIC
+    dfeats = [torch.full_like(x, float("nan")) for x in f]
+    dloc, dw = torch.full_like(l, float("nan")), torch.full_like(ww, float("nan"))
+    ws = torch.full((max(wr.backward_workspace_bytes(f, l, ww, flags), 16),), 0xFF, dtype=torch.uint8, device="cuda")
+    wr.msmv_backward_into(g, f, l, ww, dfeats, dloc, dw, workspace=ws, flags=flags)
+    ref = oracle.backward(grad_out, feats, loc, w)
+    for i, (a, r) in enumerate(zip(dfeats, ref[0])):
+        assert_close(a.cpu().numpy(), r, GRAD_RTOL, f"dfeat{i}, poisoned buffers, {algo}, P={P}", atol_floor=1e-30)
+    assert_close(dloc.cpu().numpy()[..., :2], ref[1][..., :2], GRAD_RTOL, "dloc")
+    assert float(dloc[..., 2].abs().max()) == 0.0
+    assert_close(dw.cpu().numpy(), ref[2], GRAD_RTOL, "dw")
+
+
 def test_out_of_range_view_and_nan_location(wr, oracle):
     feats, loc, w, grad_out = random_case(5, REAL_LEVELS, B=1, N=6, C=64, Q=8, P=2, oob_frac=0)
     loc[0, 0, 0, 2] = 1.3
