@@ -157,6 +157,19 @@ def test_odd_level_sizes_and_partial_patches(wr, oracle):
         _check_all(wr, oracle, feats, loc, w, grad_out)
 
 
+def test_axes_of_thousands_of_pixels(wr, oracle):
+    """Levels with one very long axis (beyond 4096 pixels the owner kernel widens its band
+    interval by a band on each side instead of relying on exact rounding), points spread over
+    the whole axis and clustered at both ends."""
+    levels = [(3, 5000), (4500, 2), (7, 4097), (1, 4096)]
+    feats, loc, w, grad_out = random_case(70, levels, B=1, N=2, C=64, Q=300, P=2, oob_frac=0.2)
+    loc[0, :40, :, 0] *= 1e-3                      # first pixels of the long axes
+    loc[0, 40:80, :, 0] = 1.0 - loc[0, 40:80, :, 0] * 1e-3
+    loc[0, 80:120, :, 1] *= 1e-3
+    loc[0, 120:160, :, 1] = 1.0 - loc[0, 120:160, :, 1] * 1e-3
+    _check_all(wr, oracle, feats, loc, w, grad_out)
+
+
 def test_many_views_and_max_points(wr, oracle):
     # 16 views is the most the owner algorithm's bin table holds; 17 must use the atomic one
     feats, loc, w, grad_out = random_case(50, TINY_LEVELS, B=1, N=16, C=64, Q=30, P=32, oob_frac=0.2)
