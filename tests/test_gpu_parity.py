@@ -157,6 +157,35 @@ def test_odd_level_sizes_and_partial_patches(wr, oracle):
         _check_all(wr, oracle, feats, loc, w, grad_out)
 
 
+def test_locations_on_band_and_pixel_boundaries(wr, oracle):
+    """Coordinates exactly on, one ulp below and one ulp above every bin-band boundary (k/32 in x,
+    k/8 in y) and every pixel boundary of every level: the sort's band of a point and the band
+    interval a patch scans are computed differently (float product vs integer division), and a
+    disagreement would drop a contribution from d feat."""
+    levels = REAL_LEVELS
+    def candidates(bands, sizes):
+        v = [k / bands for k in range(bands + 1)]
+        for n in sizes:
+            v += [i / (n - 1) for i in range(n)]
+        v = np.asarray(v, dtype=np.float32)
+        return np.unique(np.concatenate([v, np.nextafter(v, np.float32(-1)), np.nextafter(v, np.float32(2))]))
+    xs = candidates(32, [w_ for _, w_ in levels])
+    ys = candidates(8, [h for h, _ in levels])
+    rng = np.random.default_rng(88)
+    B, N, C, P = 2, 6, 64, 2
+    Q = 1200
+    feats, loc, w, grad_out = random_case(89, levels, B, N, C, Q, P, oob_frac=0.0)
+    loc[..., 0] = rng.choice(xs, size=loc.shape[:-1])
+    loc[..., 1] = rng.choice(ys, size=loc.shape[:-1])
+    # half of the points: one coordinate on a boundary, the other anywhere
+    free = rng.random(loc.shape[:-1]) < 0.5
+    axis = rng.integers(0, 2, loc.shape[:-1])
+    for ax in (0, 1):
+        m = free & (axis == ax)
+        loc[..., ax][m] = rng.random(int(m.sum())).astype(np.float32)
+    _check_all(wr, oracle, feats, loc, w, grad_out)
+
+
 def test_axes_of_thousands_of_pixels(wr, oracle):
     """Levels with one very long axis (beyond 4096 pixels the owner kernel widens its band
     interval by a band on each side instead of relying on exact rounding), points spread over
