@@ -62,7 +62,8 @@ enum {
 /* OR-ed into `flags` (owner algorithm only): run just the named stage(s) of the backward,
  * so that a profiler or benchmark can time each kernel with events of its own.  The stages
  * must be issued in this order on one stream with the same arguments and workspace; no
- * stage bit set means all three.  No counterpart in the reference. */
+ * stage bit set means all three.  `dfeats` may be NULL when STAGE_DFEAT is not among the
+ * stages asked for (see opus_msmv_dfeat_multi).  No counterpart in the reference. */
 #define OPUS_MSMV_BWD_STAGE_BIN 0x100      /* sort the points into (batch, view, band) bins */
 #define OPUS_MSMV_BWD_STAGE_DFEAT 0x200    /* d feats, one owner per run of pixels */
 #define OPUS_MSMV_BWD_STAGE_GATHER 0x400   /* d loc and d weights */
