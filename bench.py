@@ -44,8 +44,8 @@ HBM_PEAK_GBPS = 8000.0                                 # MI355X HBM3E, spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="L-fwdbwd",
                     help="{T,S,M,L}-fwd | {T,S,M,L}-fwdbwd | decoder-{T,S,M,L} (6 layers fwd+bwd) | "
                          "train-M (6 x (2 fwd + 1 bwd) + RCCL all-reduce of a 0.3 GB gradient) | "

@@ -12,22 +12,22 @@ run() { # name, args...
     timeout -k 10 300 python3 bench.py "$@" > "$O/${TAG}_bench_$name.json" 2> "$O/$name.err" || { echo "FAILED $name"; tail -3 "$O/$name.err"; exit 1; }
     echo "done $name"
 }
-run L --steps 50 --warmup 10
+run L
 for v in T S M; do run $v-fwdbwd --workload $v-fwdbwd --no-cpu-baseline; done
 run T-fwd --workload T-fwd --no-cpu-baseline
 run L-fwd --workload L-fwd --no-cpu-baseline
 run T-fwd_batch8 --workload T-fwd --batch 8 --no-cpu-baseline
-run L_batch8 --batch 8 --steps 20 --no-cpu-baseline
-run L_atomic --bwd-algo atomic --steps 20 --no-cpu-baseline
+run L_batch8 --batch 8 --steps 100 --no-cpu-baseline
+run L_atomic --bwd-algo atomic --steps 100 --no-cpu-baseline
 run L_cameras --points cameras --no-cpu-baseline
-run decoder-L --workload decoder-L --steps 20 --no-cpu-baseline
-run decoder-L_accumulate --workload decoder-L --dfeat accumulate --steps 20 --no-cpu-baseline
-run decoder-T --workload decoder-T --steps 20 --no-cpu-baseline
-run decoder-T_accumulate --workload decoder-T --dfeat accumulate --steps 20 --no-cpu-baseline
+run decoder-L --workload decoder-L --steps 100 --no-cpu-baseline
+run decoder-L_accumulate --workload decoder-L --dfeat accumulate --steps 100 --no-cpu-baseline
+run decoder-T --workload decoder-T --steps 100 --no-cpu-baseline
+run decoder-T_accumulate --workload decoder-T --dfeat accumulate --steps 100 --no-cpu-baseline
 run sampling4d-L --workload sampling4d-L --no-cpu-baseline
 run sampling4d-T --workload sampling4d-T --no-cpu-baseline
 run L_graph --graph --no-cpu-baseline
-run decoder-L_graph --workload decoder-L --graph --steps 20 --no-cpu-baseline
-run decoder-L_cameras --workload decoder-L --points cameras --steps 20 --no-cpu-baseline
+run decoder-L_graph --workload decoder-L --graph --steps 100 --no-cpu-baseline
+run decoder-L_cameras --workload decoder-L --points cameras --steps 100 --no-cpu-baseline
 timeout -k 10 200 python3 tools/bench_sampling4d.py > "$O/${TAG}_sampling4d_fusion.json" 2> "$O/fusion.err" || exit 1
 echo "bench lines under $O"

@@ -9,7 +9,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- \
-    python3 "$R/bench.py" --steps 50 --warmup 10 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/stats.err" || exit 1
+    python3 "$R/bench.py" --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/stats.err" || exit 1
 for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_REQ_sum"; do
     name=$(echo "$pass" | cut -d' ' -f1)
     timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$O/pmc_$name" -- \
