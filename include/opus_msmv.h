@@ -12,7 +12,8 @@
  *   - All tensors are fp32, contiguous, resident on the device that is current when the
  *     call is made.  Nothing is allocated, freed or synchronised inside the library; the
  *     launches are asynchronous on `stream` (a hipStream_t passed as void*, NULL = the
- *     default stream).  The library keeps no state between calls and is thread-safe.
+ *     default stream).  The library keeps no state between calls and is thread-safe; the one
+ *     exception is opus_msmv_backward_noalloc(), whose scratch is a buffer of the library's own.
  *   - feats[l]  : [B, N, H_l, W_l, C]  channel-last   (msmv_sampling.cpp:99-102)
  *     loc       : [B, Q, P, 3]  (x/width, y/height, view/(N-1)), each nominally in [0,1]
  *     weights   : [B, Q, P, L]
@@ -44,7 +45,8 @@ enum {
     OPUS_MSMV_ETOOLARGE = -5,       /* B*Q*P*C or a feature slab count exceeds the 31-bit point index */
     OPUS_MSMV_EWORKSPACE = -6,      /* workspace missing or smaller than opus_msmv_backward_workspace_bytes() */
     OPUS_MSMV_EINVAL_FLAGS = -7,    /* unknown algorithm / flag combination */
-    OPUS_MSMV_ELAUNCH = -8          /* hipGetLastError() != hipSuccess after a launch */
+    OPUS_MSMV_ELAUNCH = -8,         /* a HIP call or kernel launch of this call failed */
+    OPUS_MSMV_ESCRATCH = -9         /* opus_msmv_backward_noalloc: the sizes need more than OPUS_MSMV_NOALLOC_SCRATCH_BYTES */
 };
 
 /* backward algorithm selector (low 4 bits of `flags`) */
@@ -123,6 +125,28 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
                        int B, int C, int N, int Q, int P,
                        float *const *dfeats, float *dloc, float *dweights,
                        void *workspace, size_t workspace_bytes, int flags, void *stream);
+
+/*
+ * opus_msmv_backward for callers that cannot allocate device memory and have no workspace to
+ * hand in (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * It has no counterpart in the reference.  Same arguments, results and flags as
+ * opus_msmv_backward without `workspace` / `workspace_bytes`: the sort's scratch (bin counters,
+ * offsets and the sorted point entries, opus_msmv_backward_workspace_bytes() bytes) lives in a
+ * static device array of OPUS_MSMV_NOALLOC_SCRATCH_BYTES inside the library, one copy per GPU,
+ * held until the process ends.  Sizes that need more return OPUS_MSMV_ESCRATCH (32 MiB covers
+ * B*Q*P <= about 1.0 M points at N = 6, e.g. three OPUS-L samples); nothing is launched then.
+ * The call neither allocates nor frees nor synchronises.  The first call on a device looks the
+ * array's address up (hipGetSymbolAddress, which may load the library's code object): make it
+ * outside any graph capture.  All calls on one GPU share that GPU's array: calls that overlap
+ * in time on one GPU (two streams, two threads) race on it; calls on one stream do not.  With
+ * OPUS_MSMV_BWD_STAGE_* flags the stages of one backward must run before another backward's.
+ */
+#define OPUS_MSMV_NOALLOC_SCRATCH_BYTES (32u << 20)
+int opus_msmv_backward_noalloc(int L, const float *grad_out, const float *const *feats, const int *hw,
+                               const float *loc, const float *weights,
+                               int B, int C, int N, int Q, int P,
+                               float *const *dfeats, float *dloc, float *dweights,
+                               int flags, void *stream);
 
 /*
  * Row-mode variants: the op fused with the permute its caller applies to the result

@@ -19,6 +19,8 @@ PACK_SHARED_FRAMES = 0x1
 BWD_STAGE_BIN, BWD_STAGE_DFEAT, BWD_STAGE_GATHER = 0x100, 0x200, 0x400
 MAX_LEVELS = 8
 MAX_POINTS = 32
+NOALLOC_SCRATCH_BYTES = 32 << 20
+ESCRATCH = -9
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i32p = ctypes.POINTER(ctypes.c_int)
@@ -42,6 +44,12 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "opus_msmv_backward_noalloc": (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), _i32p,
+        ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_forward_rows": (ctypes.c_int, [
         ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _i32p, ctypes.c_void_p, ctypes.c_void_p]
         + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

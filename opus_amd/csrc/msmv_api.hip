@@ -1,13 +1,42 @@
 // C ABI of libopus_msmv.so (see include/opus_msmv.h): argument validation, the kernel
-// argument block, and dispatch to the launchers.  No allocation, no synchronisation, no
-// global state.
+// argument block, and dispatch to the launchers.  No allocation, no synchronisation; the only
+// state is the per-device address of the static scratch of opus_msmv_backward_noalloc.
 #include "../../include/opus_msmv.h"
 #include "msmv_launch.h"
 
+#include <atomic>
 #include <limits.h>
 #include <stdint.h>
 
+// Scratch of opus_msmv_backward_noalloc: the owner backward's sort workspace for callers that
+// cannot allocate.  Every GPU the library's code object is loaded on holds its own copy at its
+// own address.  In host code the name below is only a handle for hipGetSymbolAddress - it is
+// NOT a device address and must never be passed to a kernel or a HIP memory call.  (No `used`
+// attribute: it would pin the device-side symbol to local linkage, where the runtime's lookup
+// by name cannot find it; the reference from host code below is what keeps the array emitted.)
+static __device__ __align__(256) unsigned char scratch[OPUS_MSMV_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::atomic<void *> scratch_ptr[MAX_DEVICES];      // device address of `scratch`, per device ordinal
+
+// Device address of the current device's copy of `scratch` (looked up once per device; threads
+// that race here compute the same value).
+int scratch_of_current_device(void **out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
+        return OPUS_MSMV_ELAUNCH;
+    void *p = scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p)
+            return OPUS_MSMV_ELAUNCH;
+        scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return OPUS_MSMV_OK;
+}
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -86,7 +115,8 @@ const char *opus_msmv_strerror(int code)
     case OPUS_MSMV_ETOOLARGE: return "problem too large for 31-bit point / element indices";
     case OPUS_MSMV_EWORKSPACE: return "workspace missing or too small (see opus_msmv_backward_workspace_bytes)";
     case OPUS_MSMV_EINVAL_FLAGS: return "unknown algorithm or flag combination";
-    case OPUS_MSMV_ELAUNCH: return "HIP kernel launch failed";
+    case OPUS_MSMV_ELAUNCH: return "HIP call or kernel launch failed";
+    case OPUS_MSMV_ESCRATCH: return "sizes need more scratch than the library's static buffer (OPUS_MSMV_NOALLOC_SCRATCH_BYTES)";
     default: return "unknown error code";
     }
 }
@@ -233,6 +263,26 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
 {
     return backward_impl(L, grad_out, feats, hw, loc, weights, B, 0, 0, C, N, Q, P, dfeats, dloc, dweights,
                          workspace, workspace_bytes, flags, stream);
+}
+
+int opus_msmv_backward_noalloc(int L, const float *grad_out, const float *const *feats, const int *hw,
+                               const float *loc, const float *weights,
+                               int B, int C, int N, int Q, int P,
+                               float *const *dfeats, float *dloc, float *dweights,
+                               int flags, void *stream)
+{
+    // 0 where no scratch is needed (atomic algorithm, shapes the owner algorithm does not take)
+    const size_t need = opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags);
+    if (need > OPUS_MSMV_NOALLOC_SCRATCH_BYTES)
+        return OPUS_MSMV_ESCRATCH;
+    void *ptr = nullptr;
+    const int rc = scratch_of_current_device(&ptr);
+    if (rc != OPUS_MSMV_OK)
+        return rc;
+    // the sort clears the counters it needs itself (hipMemsetAsync on `stream`) and overwrites
+    // offsets and entries: whatever an earlier call left in the array is never read
+    return backward_impl(L, grad_out, feats, hw, loc, weights, B, 0, 0, C, N, Q, P, dfeats, dloc, dweights,
+                         ptr, OPUS_MSMV_NOALLOC_SCRATCH_BYTES, flags, stream);
 }
 
 int opus_msmv_backward_rows(int L, const float *grad_out, const float *const *feats, const int *hw,
