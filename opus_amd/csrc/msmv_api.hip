@@ -187,7 +187,7 @@ size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int
     if (L < 1 || B < 0 || N < 1 || Q < 0 || P < 1)
         return 0;
     MsmvArgs a = {};
-    a.C = C; a.L = L;
+    a.C = C; a.L = L; a.N = N;
     if (!msmv_backward_owner_supported(a))
         return 0;
     return msmv_backward_owner_workspace(B, N, Q, P);
@@ -222,7 +222,11 @@ static int backward_impl(int L, const float *grad_out, const float *const *feats
         a.lvl[l].feat = feats[l];
         a.lvl[l].dfeat = dfeats ? dfeats[l] : nullptr;
     }
-    if (a.npts > 0 && (!grad_out || !loc || !weights || !dloc || !dweights))
+    // d loc / d weights are written by the gather stage and, for points without a valid view, by
+    // the sort stage; the d-feat stage alone leaves them alone
+    const bool need_dlw = algo != OPUS_MSMV_BWD_OWNER || !stage_bits ||
+                          (stage_bits & (OPUS_MSMV_BWD_STAGE_BIN | OPUS_MSMV_BWD_STAGE_GATHER));
+    if (a.npts > 0 && (!grad_out || !loc || !weights || (need_dlw && (!dloc || !dweights))))
         return OPUS_MSMV_EINVAL_PTR;
     a.loc = loc;
     a.w = weights;

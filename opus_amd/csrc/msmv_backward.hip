@@ -1175,13 +1175,12 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const MsmvTap &t = tap[l];
-            const float m1 = t.c1 ? 1.f : 0.f, m2 = t.c2 ? 1.f : 0.f;
-            const float m3 = t.c3 ? 1.f : 0.f, m4 = t.c4 ? 1.f : 0.f;
+            // (an out-of-image corner's value is discarded, not multiplied by 0: see the forward)
             float sval = 0.f, sgw = 0.f, sgh = 0.f;
 #define MSMV_GATHER_CH(X)                                                          \
             {                                                                      \
-                const float v1 = m1 * v[l][0].X, v2 = m2 * v[l][1].X;              \
-                const float v3 = m3 * v[l][2].X, v4 = m4 * v[l][3].X;              \
+                const float v1 = t.c1 ? v[l][0].X : 0.f, v2 = t.c2 ? v[l][1].X : 0.f; \
+                const float v3 = t.c3 ? v[l][2].X : 0.f, v4 = t.c4 ? v[l][3].X : 0.f; \
                 const float val = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;   \
                 sval += gq.X * val;                                                \
                 sgw += gq.X * (t.hh * (v2 - v1) + t.lh * (v4 - v3));               \
@@ -1206,7 +1205,7 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
 }
 
 template <int NL>
-hipError_t launch_gather(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
+void launch_gather(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
 {
     const int ngroups = (a.npts + 3) / 4;
     const int per_block = (GAT_THREADS / 64) * GAT_GROUPS_PER_WAVE;
@@ -1220,7 +1219,6 @@ hipError_t launch_gather(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
     case 4: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 4, false>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     default: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 0, false>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     }
-    return hipGetLastError();
 }
 
 }  // namespace
@@ -1230,6 +1228,7 @@ hipError_t launch_gather(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
 // ======================================================================================
 hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool accumulate)
 {
+    const hipError_t stale = hipPeekAtLastError();
     if (!accumulate) {
         for (int l = 0; l < a.L; ++l) {
             const size_t bytes = (size_t)a.B * a.N * a.lvl[l].H * a.lvl[l].W * a.C * sizeof(float);
@@ -1248,7 +1247,7 @@ hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool ac
     if (nblk < 1)
         nblk = 1;
     hipLaunchKernelGGL(msmv_bwd_atomic, dim3(nblk), dim3(64 * wpb), 0, s, a);
-    return hipGetLastError();
+    return msmv_launch_status(stale);
 }
 
 bool msmv_backward_owner_supported(const MsmvArgs &a)
@@ -1325,7 +1324,7 @@ static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hi
         else
             launch_owner_dfeat<false, false>(pt, grid, block, s, a, sets, geo);
     }
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t msmv_launch_dfeat_sets(const MsmvArgs &a, int nsets, const float *const *gouts,
@@ -1341,7 +1340,9 @@ hipError_t msmv_launch_dfeat_sets(const MsmvArgs &a, int nsets, const float *con
         sets.offsets[i] = ws.offsets;
         sets.entries[i] = ws.entries;
     }
-    return launch_dfeat_sets(a, sets, s, accumulate);
+    const hipError_t stale = hipPeekAtLastError();
+    const hipError_t e = launch_dfeat_sets(a, sets, s, accumulate);
+    return e != hipSuccess ? e : msmv_launch_status(stale);
 }
 
 int msmv_dfeat_max_sets() { return OWN_MAX_SETS; }
@@ -1349,12 +1350,11 @@ int msmv_dfeat_max_sets() { return OWN_MAX_SETS; }
 hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate)
 {
     const OwnerWs ws = owner_ws_of(a, workspace);
+    const hipError_t stale = hipPeekAtLastError();
 
     hipError_t e;
     if ((stages & 1) && a.qp > 0 && a.qp <= BIN_ONE_PPT * BIN_THREADS) {
         hipLaunchKernelGGL(msmv_bin_one, dim3((unsigned)a.B), dim3(BIN_THREADS), 0, s, a, ws);
-        if ((e = hipGetLastError()) != hipSuccess)
-            return e;
     } else if (stages & 1) {
         if ((e = hipMemsetAsync(workspace, 0, owner_ws_clear_bytes(a.B, a.N), s)) != hipSuccess)
             return e;
@@ -1368,9 +1368,9 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
             if (e != hipSuccess)
                 return e;
         }
-        if ((e = hipGetLastError()) != hipSuccess)
-            return e;
     }
+    if ((e = msmv_launch_status(stale)) != hipSuccess)
+        return e;
 
     if (stages & 2) {
         OwnerSets sets = {};
@@ -1381,9 +1381,11 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
         if ((e = launch_dfeat_sets(a, sets, s, accumulate)) != hipSuccess)
             return e;
     }
-    if ((e = hipGetLastError()) != hipSuccess)
-        return e;
-    if (a.npts > 0 && (stages & 4))
-        return a.L == 4 ? launch_gather<4>(a, ws, s) : launch_gather<5>(a, ws, s);
-    return hipSuccess;
+    if (a.npts > 0 && (stages & 4)) {
+        if (a.L == 4)
+            launch_gather<4>(a, ws, s);
+        else
+            launch_gather<5>(a, ws, s);
+    }
+    return msmv_launch_status(stale);
 }

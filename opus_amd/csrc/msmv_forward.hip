@@ -103,14 +103,18 @@ msmv_fwd_c64(const MsmvArgs a)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const MsmvTap &t = tap[l];
-            // an out-of-image corner counts as a zero value (forward.cu:48-67)
-            const float w1 = t.c1 ? t.w1 : 0.f, w2 = t.c2 ? t.w2 : 0.f;
-            const float w3 = t.c3 ? t.w3 : 0.f, w4 = t.c4 ? t.w4 : 0.f;
+            // an out-of-image corner counts as a zero VALUE (forward.cu:48-67): what was loaded for
+            // it (a clamped in-image pixel) is discarded, so that a non-finite neighbour cannot
+            // turn 0 * inf into NaN
+#define MSMV_FWD_CH(X)                                                             \
+            {                                                                      \
+                const float v1 = t.c1 ? v[l][0].X : 0.f, v2 = t.c2 ? v[l][1].X : 0.f; \
+                const float v3 = t.c3 ? v[l][2].X : 0.f, v4 = t.c4 ? v[l][3].X : 0.f; \
+                val.X = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;             \
+            }
             float4 val;
-            val.x = w1 * v[l][0].x + w2 * v[l][1].x + w3 * v[l][2].x + w4 * v[l][3].x;
-            val.y = w1 * v[l][0].y + w2 * v[l][1].y + w3 * v[l][2].y + w4 * v[l][3].y;
-            val.z = w1 * v[l][0].z + w2 * v[l][1].z + w3 * v[l][2].z + w4 * v[l][3].z;
-            val.w = w1 * v[l][0].w + w2 * v[l][1].w + w3 * v[l][2].w + w4 * v[l][3].w;
+            MSMV_FWD_CH(x) MSMV_FWD_CH(y) MSMV_FWD_CH(z) MSMV_FWD_CH(w)
+#undef MSMV_FWD_CH
             // a level that is out of range adds nothing at all (forward.cu:126)
             acc.x = t.ok ? acc.x + val.x * wl[l] : acc.x;
             acc.y = t.ok ? acc.y + val.y * wl[l] : acc.y;
@@ -201,7 +205,7 @@ msmv_fwd_generic(const MsmvArgs a)
 }
 
 template <int NL>
-hipError_t launch_c64(const MsmvArgs &a, hipStream_t s)
+void launch_c64(const MsmvArgs &a, hipStream_t s)
 {
     const int ngroups = (a.npts + 3) / 4;
     const int per_block = (FWD_THREADS / 64) * FWD_GROUPS_PER_WAVE;
@@ -213,7 +217,6 @@ hipError_t launch_c64(const MsmvArgs &a, hipStream_t s)
     case 4: hipLaunchKernelGGL((msmv_fwd_c64<NL, 4>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
     default: hipLaunchKernelGGL((msmv_fwd_c64<NL, 0>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
     }
-    return hipGetLastError();
 }
 
 }  // namespace
@@ -222,14 +225,17 @@ hipError_t msmv_launch_forward(const MsmvArgs &a, hipStream_t s, int force_gener
 {
     if (a.npts == 0)
         return hipSuccess;
-    if (!force_generic && a.C == 64 && a.L == 4)
-        return launch_c64<4>(a, s);
-    if (!force_generic && a.C == 64 && a.L == 5)
-        return launch_c64<5>(a, s);
-    const int waves_per_block = 4;
-    int nblk = (a.npts + waves_per_block - 1) / waves_per_block;
-    if (nblk > 256 * 32)
-        nblk = 256 * 32;
-    hipLaunchKernelGGL(msmv_fwd_generic, dim3(nblk), dim3(64 * waves_per_block), 0, s, a);
-    return hipGetLastError();
+    const hipError_t stale = hipPeekAtLastError();
+    if (!force_generic && a.C == 64 && a.L == 4) {
+        launch_c64<4>(a, s);
+    } else if (!force_generic && a.C == 64 && a.L == 5) {
+        launch_c64<5>(a, s);
+    } else {
+        const int waves_per_block = 4;
+        int nblk = (a.npts + waves_per_block - 1) / waves_per_block;
+        if (nblk > 256 * 32)
+            nblk = 256 * 32;
+        hipLaunchKernelGGL(msmv_fwd_generic, dim3(nblk), dim3(64 * waves_per_block), 0, s, a);
+    }
+    return msmv_launch_status(stale);
 }

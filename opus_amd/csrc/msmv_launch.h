@@ -3,6 +3,20 @@
 #include "msmv_common.h"
 #include <stddef.h>
 
+// Launch errors are read from the thread's "last error" slot, which other users of the HIP
+// runtime in the process (e.g. torch) share.  A launcher notes the slot's state before its first
+// launch (`stale = hipPeekAtLastError()`) and ends with msmv_launch_status(stale): an error its own
+// launches raised is returned and taken out of the slot; one that was already there is neither
+// reported as ours nor consumed.
+inline hipError_t msmv_launch_status(hipError_t stale)
+{
+    const hipError_t now = hipPeekAtLastError();
+    if (now == hipSuccess || now == stale)
+        return hipSuccess;
+    (void)hipGetLastError();
+    return now;
+}
+
 // force_generic != 0 selects the any-shape kernel even when the fast path applies (testing).
 hipError_t msmv_launch_forward(const MsmvArgs &a, hipStream_t s, int force_generic);
 

@@ -52,6 +52,19 @@ __device__ __forceinline__ ProjIndex proj_index(long long idx, const ProjDims &d
     return r;
 }
 
+// Row r of M * (x, y, z, 1) as three rounded products summed left to right, every operation
+// rounded on its own (no fused multiply-add): the camera choice below is index work, and a
+// visibility test that sits on its threshold must fall the same way as in the plain float32
+// statement of the projection (opus_sampling.py:54 computes it as a float32 matrix product).
+// (The pragma, not __fmul_rn / __fadd_rn: those are plain * and + to the compiler, which
+// contracts them into fused multiply-adds under HIP's default fp-contract=fast.)
+__device__ __forceinline__ float proj_row(const float *M, float x, float y, float z)
+{
+#pragma clang fp contract(off)
+    const float a = M[0] * x, b = M[1] * y, c = M[2] * z;
+    return ((a + b) + c) + M[3];
+}
+
 __global__ void __launch_bounds__(256)
 msmv_project_pack_fwd(const float *__restrict__ pts, const float *__restrict__ sw,
                       const float *__restrict__ occ2img, ProjDims d,
@@ -68,11 +81,11 @@ msmv_project_pack_fwd(const float *__restrict__ pts, const float *__restrict__ s
     int view = -1;
     for (int n = 0; n < d.N; ++n, M += 16) {
         // rows 0..2 of M * (x, y, z, 1)   (opus_sampling.py:54)
-        const float cx = M[0] * x + M[1] * y + M[2] * z + M[3];
-        const float cy = M[4] * x + M[5] * y + M[6] * z + M[7];
-        const float cz = M[8] * x + M[9] * y + M[10] * z + M[11];
+        const float cx = proj_row(M, x, y, z);
+        const float cy = proj_row(M + 4, x, y, z);
+        const float cz = proj_row(M + 8, x, y, z);
         const float hz = fmaxf(cz, d.eps);                            // :58
-        const float u = (cx / hz) / d.image_w;                        // :59, :62
+        const float u = (cx / hz) / d.image_w;                        // :59, :62 (two correctly rounded divisions)
         const float v = (cy / hz) / d.image_h;                        // :63
         const bool valid = cz > d.eps && v > 0.f && v < 1.f && u > 0.f && u < 1.f;   // :66-70
         // first valid camera wins; camera 0 is the default when none is valid (:94)
@@ -201,8 +214,9 @@ hipError_t msmv_launch_project_pack(const float *pts, const float *sw, const flo
     if (d.npts == 0)
         return hipSuccess;
     const unsigned nblk = (unsigned)((d.npts + 255) / 256);
+    const hipError_t stale = hipPeekAtLastError();
     hipLaunchKernelGGL(msmv_project_pack_fwd, dim3(nblk), dim3(256), 0, s, pts, sw, occ2img, d, loc, w);
-    return hipGetLastError();
+    return msmv_launch_status(stale);
 }
 
 hipError_t msmv_launch_project_pack_backward(const float *dloc, const float *dw, const float *pts,
@@ -214,13 +228,14 @@ hipError_t msmv_launch_project_pack_backward(const float *dloc, const float *dw,
     const ProjDims d = make_dims(B, Q, T, G, P, L, N, image_h, image_w, eps, shared);
     if (d.npts == 0)
         return hipSuccess;
+    const hipError_t stale = hipPeekAtLastError();
     if (shared) {
         const long long nsrc = (long long)B * Q * G * P;
         hipLaunchKernelGGL(msmv_project_pack_bwd_shared, dim3((unsigned)((nsrc + 255) / 256)), dim3(256), 0, s,
                            dloc, dw, pts, occ2img, loc, d, dpts, dsw);
-        return hipGetLastError();
+        return msmv_launch_status(stale);
     }
     const unsigned nblk = (unsigned)((d.npts + 255) / 256);
     hipLaunchKernelGGL(msmv_project_pack_bwd, dim3(nblk), dim3(256), 0, s, dloc, dw, pts, occ2img, loc, d, dpts, dsw);
-    return hipGetLastError();
+    return msmv_launch_status(stale);
 }

@@ -170,6 +170,7 @@ hipError_t msmv_launch_relayout(const float *src, float *dst, int B, int T, int 
     const bool vec = (d.S % 4 == 0) && (C % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
     const dim3 grid((unsigned)nblk), block(RL_THREADS);
+    const hipError_t stale = hipPeekAtLastError();
     if (!inverse) {
         if (vec) hipLaunchKernelGGL((msmv_relayout_kernel<false, true>), grid, block, 0, s, src, dst, d);
         else     hipLaunchKernelGGL((msmv_relayout_kernel<false, false>), grid, block, 0, s, src, dst, d);
@@ -177,5 +178,5 @@ hipError_t msmv_launch_relayout(const float *src, float *dst, int B, int T, int 
         if (vec) hipLaunchKernelGGL((msmv_relayout_kernel<true, true>), grid, block, 0, s, src, dst, d);
         else     hipLaunchKernelGGL((msmv_relayout_kernel<true, false>), grid, block, 0, s, src, dst, d);
     }
-    return hipGetLastError();
+    return msmv_launch_status(stale);
 }

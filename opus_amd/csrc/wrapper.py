@@ -13,32 +13,52 @@ and ``from .csrc.wrapper import MSMV_CUDA`` (models/opus_transformer.py:14) keep
 Differences, all deliberate:
   * the native code is a C-ABI shared library reached through ctypes (opus_amd/_lib.py),
     launched on the caller's current HIP stream and device;
-  * ``msmv_sampling`` never silently falls back: with the library missing it raises.  A
-    caller that wants the grid_sample formulation calls ``msmv_sampling_pytorch`` itself;
+  * by default ``msmv_sampling`` never silently falls back: with the library missing it raises
+    (and on a machine with a GPU the import itself fails).  The reference's behaviour - warn at
+    import, ``MSMV_CUDA = False``, ``msmv_sampling`` -> ``msmv_sampling_pytorch`` on channel-first
+    features (wrapper.py:8-11, :87-93) - is an explicit opt-in: environment variable
+    ``OPUS_MSMV_ALLOW_FALLBACK=1`` (read at import) or ``allow_fallback(True)``.  With the
+    library loaded the HIP path always runs; the opt-in never routes around it;
   * launch failures raise ``RuntimeError`` (the reference prints and continues,
     msmv_sampling_forward.cu:295-298);
   * the gradient buffers are allocated here with ``torch.empty`` and fully written by the
     library (the reference's host shim allocates zeros, msmv_sampling.cpp:244-249).
 """
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
 
 from .. import _lib
 
+_allow_fallback = os.environ.get("OPUS_MSMV_ALLOW_FALLBACK", "0") not in ("", "0")
+
 try:
     _lib.load()
     MSMV_CUDA = True
 except ImportError as e:
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() and not _allow_fallback:
         # a GPU is present but the extension is not: that is a broken install, not a
         # configuration to limp along in
         raise
-    print('Warning: failed to load the HIP extension libopus_msmv.so; '
-          'msmv_sampling() will raise, only msmv_sampling_pytorch() is usable.')
+    if _allow_fallback:
+        print('Warning: failed to load the HIP extension libopus_msmv.so, performance may be hurt: '
+              'msmv_sampling() uses the grid_sample formulation (OPUS_MSMV_ALLOW_FALLBACK is set).')
+    else:
+        print('Warning: failed to load the HIP extension libopus_msmv.so; '
+              'msmv_sampling() will raise, only msmv_sampling_pytorch() is usable '
+              '(set OPUS_MSMV_ALLOW_FALLBACK=1 for the reference\'s silent fallback).')
     print('Error message:', e)
     MSMV_CUDA = False
+
+
+def allow_fallback(flag=True):
+    """Opt in to (or out of) the reference dispatcher's fallback arm (wrapper.py:87-93): when the
+    library is not loaded, ``msmv_sampling`` returns ``msmv_sampling_pytorch(...)`` on
+    channel-first features instead of raising."""
+    global _allow_fallback
+    _allow_fallback = bool(flag)
 
 _BWD_ALGOS = {"auto": _lib.BWD_AUTO, "atomic": _lib.BWD_ATOMIC, "owner": _lib.BWD_OWNER}
 _bwd_algo = os.environ.get("OPUS_MSMV_BWD_ALGO", "auto")
@@ -310,9 +330,12 @@ class FeatureGradSink:
 
     def __init__(self, mlvl_feats, defer=None):
         self.feats = [f.detach() for f in mlvl_feats]
+        # the detached aliases are invisible to autograd's saved-tensor version check: an in-place
+        # update of a feature map between forward and backward is caught by comparing these
+        self._versions = [f._version for f in mlvl_feats]
         if defer is None:
             B, N, _, _, C = self.feats[0].shape     # non-zero workspace <=> the owner algorithm applies
-            defer = _bwd_algo != "atomic" and \
+            defer = _bwd_algo != "atomic" and all(f.data_ptr() % 16 == 0 for f in self.feats) and \
                 _lib.load().opus_msmv_backward_workspace_bytes(len(self.feats), B, C, N, 1, 1, 0) > 0
         self.defer = bool(defer)
         self.pending = []                       # deferred: (grad_output, workspace, Q, P, rows) per layer
@@ -322,16 +345,31 @@ class FeatureGradSink:
     def __len__(self):
         return len(self.feats)
 
+    def check_versions(self):
+        for i, (f, v) in enumerate(zip(self.feats, self._versions)):
+            if f._version != v:
+                raise RuntimeError(
+                    f"one of the variables needed for gradient computation has been modified by an inplace "
+                    f"operation: feature level {i} of a FeatureGradSink is at version {f._version}; "
+                    f"expected version {v} instead")
+
 
 class _SinkOpen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sink, *feats):
-        ctx.sink = sink
+        # weak: sink.token's grad_fn is this node, a strong reference would close the cycle
+        # sink -> token -> node -> sink and keep the sink's aliases of the feature maps (735 MB
+        # per sample) alive until a cyclic collection.  The layers' nodes hold the sink strongly.
+        ctx.sink_ref = weakref.ref(sink)
+        ctx.n_feats = len(feats)
         return torch.zeros((), dtype=torch.float32, device=feats[0].device)
 
     @staticmethod
     def backward(ctx, _gtoken):
-        sink = ctx.sink
+        sink = ctx.sink_ref()
+        if sink is None:                        # no layer ever sampled through the sink
+            return (None,) * (1 + ctx.n_feats)
+        sink.check_versions()
         if sink.pending:
             # one pass per group of layers with equal sizes, at most max_sets layers per launch
             first = sink.buffers is None
@@ -364,8 +402,11 @@ class _MSMVSamplingSink(torch.autograd.Function):
     def backward(ctx, grad_output):
         sink = ctx.sink
         sampling_locations, scale_weights = ctx.saved_tensors
+        sink.check_versions()
         if sink.defer:
             g = grad_output.contiguous()
+            if g.data_ptr() % 16:               # (a contiguous view at an odd offset)
+                g = g.clone()
             flags = _lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER
             need = backward_workspace_bytes(sink.feats, sampling_locations, scale_weights, flags)
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=g.device)
@@ -400,7 +441,14 @@ def msmv_sampling_rows(mlvl_feats, sampling_locations, scale_weights, num_frames
 
 def msmv_sampling(mlvl_feats, sampling_locations, scale_weights):
     """Channel-last features [B,N,H,W,C] per level -> [B,Q,C,P] (reference wrapper.py:87-93).
-    ``mlvl_feats`` may be a FeatureGradSink (no counterpart in the reference)."""
+    ``mlvl_feats`` may be a FeatureGradSink (no counterpart in the reference).
+
+    Without the library: raises, unless the fallback was opted into (``allow_fallback`` /
+    OPUS_MSMV_ALLOW_FALLBACK=1) - then, as the reference's last arm (wrapper.py:92-93), the
+    features are taken channel-FIRST [B,C,N,H,W] (what the decoder prepares when MSMV_CUDA is
+    false, models/opus_transformer.py:122-124) and ``msmv_sampling_pytorch`` computes the result."""
+    if not MSMV_CUDA and _allow_fallback:
+        return msmv_sampling_pytorch(mlvl_feats, sampling_locations, scale_weights)
     sink = _sink_or_none(mlvl_feats)
     if sink is not None:
         return _MSMVSamplingSink.apply(sink, None, sink.token, sampling_locations, scale_weights)

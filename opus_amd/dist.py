@@ -9,6 +9,10 @@ ROCm) is used only for rendezvous, barriers, timing reductions and - in a traini
 configuration - the parameter-gradient all-reduce that lives outside the op.
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 
@@ -68,3 +72,44 @@ def fence(dist, device=None):
         dist.barrier()
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(world, argv, env=None, poll_s=0.2):
+    """Start `world` fresh interpreter processes running `argv` (script + arguments), one per
+    rank, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port), and wait for all of them.
+
+    For a caller that was started WITHOUT a launcher although it is to use several GPUs.  The
+    caller must not have touched the GPU: the children are new processes (fork + exec of the
+    interpreter), never a re-exec of this one.  Their stdout / stderr are the caller's, so the
+    one line rank 0 prints is this process's output.  Returns the exit status to leave with:
+    0 if every rank returned 0, else the first failing rank's status; when one rank fails, the
+    others (exactly the processes started here) are terminated instead of left waiting in a
+    collective."""
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    procs = []
+    for rank in range(world):
+        e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    status = 0
+    live = set(range(world))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 128 - rc
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            time.sleep(poll_s)
+    return status

@@ -42,6 +42,21 @@ def relayout_features_torch(mlvl_feats, num_frames, num_views, num_groups):
     return out
 
 
+def relayout_features_channel_first(mlvl_feats, num_frames, num_views, num_groups):
+    """[B, T*N, G*C, H, W] per level -> [B*T*G, C, N, H, W] contiguous: the layout the decoder
+    prepares for the grid_sample fallback when MSMV_CUDA is false
+    (models/opus_transformer.py:122-124)."""
+    out = []
+    for feat in mlvl_feats:
+        B, TN, GC, H, W = feat.shape
+        T, N, G = num_frames, num_views, num_groups
+        assert TN == T * N and GC % G == 0
+        C = GC // G
+        feat = feat.reshape(B, T, N, G, C, H, W).permute(0, 1, 3, 4, 2, 5, 6)
+        out.append(feat.reshape(B * T * G, C, N, H, W).contiguous())
+    return out
+
+
 class _Relayout(torch.autograd.Function):
     """opus_msmv_relayout behind autograd: a tiled transpose forward, its inverse backward."""
 

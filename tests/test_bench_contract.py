@@ -42,8 +42,18 @@ def test_result_line_carries_every_contract_field():
     assert abs(r["value"] - 32 * 600 * 4 / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
     roof = r["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    # achieved counts compulsory bytes: a true fraction of the peak; the no-reuse figure sits beside it
     assert roof["achieved"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
-    assert "traffic" in roof
+    assert roof["frac"] <= 1.0 and roof["achieved_alg"] >= roof["achieved"]
+    k = r["kernels"][roof["kernel"]]
+    assert abs(roof["achieved"] - k["compulsory_bytes"] / (k["avg_us"] * 1e-6) / 1e9) <= 1e-6 * roof["achieved"]
+    # no PMC pass of this configuration (OPUS-T, 4 steps) is committed: null, not a borrowed figure
+    assert "traffic" in roof and roof["traffic"] is None
+    # the whole-pass algorithmic bytes are the contract's: 4380 B/point forward, 8504 B/point + F backward
+    npts, F = 32 * 600 * 4, 32 * 6 * 14960 * 64 * 4
+    assert abs(r["step_alg_GBps"] * r["ms_per_step"] * 1e6 - (npts * (4380 + 8504) + F)) <= 1e-6 * F
+    alg = {n: v["alg_bytes"] for n, v in r["kernels"].items() if "alg_bytes" in v}
+    assert alg["msmv_bwd_owner_dfeat"] + alg["msmv_bwd_gather_c64"] == npts * 8504 + F
     cpu = r["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0
     assert cpu["unit"] == r["unit"] and cpu["sample"]
@@ -61,6 +71,24 @@ def test_decoder_workload_runs_in_both_dfeat_modes(mode):
     else:
         assert {"msmv_bwd_owner_dfeat", "msmv_bwd_owner_dfeat(accumulate)"} <= names
     assert r["config"]["points_per_step_per_gpu"] == 6 * 32 * 600 * 4
+
+
+@pytest.mark.gpu
+def test_training_step_workload_runs_on_one_gpu():
+    """OPUS-M training-step shape on one rank: six layers x (2 forwards + 1 backward); the
+    gradient all-reduce has no peer at N = 1 (its two-rank path runs under gloo in
+    tests/test_dist_gloo.py)."""
+    r = run_bench("--workload", "train-M", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert r["config"]["points_per_step_per_gpu"] == 6 * 32 * 2400 * 2
+    assert r["kernels"]["msmv_fwd_c64"]["launches"] == 12       # 6 layers x 2 forwards in the evented step
+    assert r["value"] > 0
+
+
+@pytest.mark.gpu
+def test_self_launch_with_one_gpu_is_the_plain_run():
+    r = run_bench("--gpus", "1", "--workload", "T-fwd", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert r["n_gpus"] == 1 and r["config"]["backend"] is None
+    assert r["config"]["ranks"] == [{"rank": 0, "seed": 1234, "slabs": [0, 32], "device": "cuda:0"}]
 
 
 @pytest.mark.gpu

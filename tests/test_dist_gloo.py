@@ -76,3 +76,71 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+# ---- bench.py's own multi-rank control flow, compute stubbed (no GPU): launch -> per-rank seeds
+# and slab ranges -> fence -> slowest rank's time -> ONE line from rank 0
+def _bench_line(cmd):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable] + cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_stubbed(launcher):
+    args = ["bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--stub-compute", "--workload", "L-fwdbwd"]
+    if launcher == "torchrun":
+        args = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] + args
+    r = _bench_line(args)
+    assert r["n_gpus"] == 2 and r["steps"] == 6 and r["warmup"] == 2 and r["data"] == "stub"
+    assert r["scaling"] == "weak" and r["config"]["backend"] == "gloo"
+    assert [(x["rank"], x["seed"], x["slabs"]) for x in r["config"]["ranks"]] == \
+        [(0, 1234, [0, 32]), (1, 1235, [32, 64])]
+    # rank 1 sleeps 4 ms per step, rank 0 only 2 ms: the job's time is the slowest rank's
+    assert r["ms_per_step"] >= 4.0
+    # value = points of ALL ranks / that time
+    assert abs(r["value"] - 2 * 32 * 4800 * 2 / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+
+
+def test_bench_split_sample_and_allreduce_stubbed():
+    r = _bench_line(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-compute",
+                     "--workload", "T-fwd", "--split-sample"])
+    assert r["scaling"] == "strong"
+    assert [x["slabs"] for x in r["config"]["ranks"]] == [[0, 16], [16, 32]]
+    assert abs(r["value"] - 32 * 600 * 4 / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+    # the training configuration's gradient all-reduce (12 buckets of 25 MB) between two ranks
+    r = _bench_line(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-compute",
+                     "--workload", "train-M"])
+    assert r["config"]["points_per_step_per_gpu"] == 6 * 32 * 2400 * 2 and r["n_gpus"] == 2
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--stub-compute"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "does not match" in p.stderr
+
+
+def test_spawn_ranks_reports_a_failing_rank():
+    import sys
+    from opus_amd.dist import spawn_ranks
+    code = "import os, sys, time; r = int(os.environ['RANK']); time.sleep(0.2 if r else 30); sys.exit(7 if r else 0)"
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+    try:
+        assert spawn_ranks(2, [f.name]) == 7          # rank 1 fails; rank 0 (asleep) is terminated, not awaited
+    finally:
+        os.unlink(f.name)

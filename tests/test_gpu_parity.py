@@ -384,7 +384,8 @@ def _device_case(B, Q, P, seed, levels=REAL_LEVELS, N=6, C=64):
     return feats, loc, w, g
 
 
-@pytest.mark.parametrize("shape", [(32, 4800, 2), (32, 600, 4)], ids=["OPUS-L", "OPUS-T"])
+@pytest.mark.parametrize("shape", [(32, 4800, 2), (32, 2400, 2), (32, 1200, 2), (32, 600, 4)],
+                         ids=["OPUS-L", "OPUS-M", "OPUS-S", "OPUS-T"])
 def test_full_size_adjoint_identities(wr, shape):
     """At the benchmark sizes the oracle is too slow; use what linearity gives for free:
     the op is linear in feats and in weights, so <g, F(feats, w)> = <dfeats, feats> = <dw, w>,
@@ -532,3 +533,89 @@ def test_randomised_shapes_against_the_oracle(wr, oracle):
                 assert_close(a_.cpu().numpy(), b_.cpu().numpy(), GRAD_RTOL, what + " row-mode dfeat")
             assert_close(dl_r.cpu().numpy(), dl_p.cpu().numpy(), 1e-5, what + " row-mode dloc")
             assert_close(dw_r.cpu().numpy(), dw_p.cpu().numpy(), 1e-5, what + " row-mode dw")
+
+
+def test_non_finite_border_pixel_is_treated_as_the_reference_does(wr, oracle):
+    """An out-of-image corner has the VALUE zero in the reference (msmv_sampling_forward.cu:48-67:
+    the load is skipped), so an infinite feature next to the border reaches the output only through
+    the corners that really lie on it - as +-inf, never as the NaN of 0 * inf.  All forward and
+    backward kernels must agree with the oracle on where the non-finite values are."""
+    feats, loc, w, grad_out = random_case(99, REAL_LEVELS, B=2, N=6, C=64, Q=40, P=2, oob_frac=0.0)
+    w = np.abs(w) + 0.05
+    w /= w.sum(-1, keepdims=True)
+    w = w.astype(np.float32)
+    H, W = REAL_LEVELS[0]
+    feats[0][0, 2, 10, W - 1, 7] = np.inf           # right border
+    feats[0][1, 4, 0, 33, 5] = -np.inf              # top border
+    loc[0, :8, 0] = [1.0, (10 + 0.25) / (H - 1), 2 / 5]          # exactly on the last column: corner 2 is outside
+    loc[0, 8:16, 0] = [1.0 + 0.3 / (W - 1), 10 / (H - 1), 2 / 5]  # beyond it, still in range
+    loc[1, :8, 1] = [(33 + 0.5) / (W - 1), -0.4 / (H - 1), 4 / 5]  # above the first row
+    ref_out = oracle.forward(feats, loc, w)
+    assert np.isinf(ref_out).any() and not np.isnan(ref_out).any()
+    _, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
+
+    def same_non_finite(a, b, what):
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{what}: NaN pattern"
+        assert np.array_equal(np.isposinf(a), np.isposinf(b)) and np.array_equal(np.isneginf(a), np.isneginf(b)), \
+            f"{what}: inf pattern"
+        fin = np.isfinite(b)
+        assert_close(a[fin], b[fin], GRAD_RTOL, what)
+
+    for flags, name in ((0, "fast"), (1, "generic")):
+        same_non_finite(run_hip(wr, feats, loc, w, flags=flags), ref_out, f"forward [{name}]")
+    for algo in ALGOS:
+        _, _, dloc, dw = run_hip(wr, feats, loc, w, grad_out, algo=algo)
+        same_non_finite(dw, ref_dw, f"dw [{algo}]")
+        same_non_finite(dloc, ref_dloc, f"dloc [{algo}]")
+
+
+@pytest.mark.parametrize("mode", ["deferred", "accumulate"])
+def test_full_size_six_layer_decoder_step(wr, oracle, mode):
+    """The full decoder configuration at OPUS-L size: six layers (six point sets) sample the same
+    feature maps (B' = 32 slabs, Q = 4800, P = 2), forward + backward with the layers' d feats
+    summed into ONE buffer - deferred to a single multi-set pass, or accumulated layer by layer.
+    The sum must equal the sum of six stand-alone backwards of the atomic algorithm (the other
+    implementation) everywhere, and the oracle's sum over the six layers on the last slab."""
+    from opus_amd import _lib
+    B, Q, P, NL = 32, 4800, 2, 6
+    feats, loc0, w0, g0 = _device_case(B, Q, P, seed=4321)
+    layers = [(loc0, w0, g0)] + [_device_case(B, Q, P, seed=4322 + i)[1:] for i in range(NL - 1)]
+    # reference sum: atomic algorithm, one layer at a time, accumulating (its own flag path)
+    ref = [torch.zeros_like(f) for f in feats]
+    ref_small = []
+    for loc, w, g in layers:
+        _, dloc, dw = wr.msmv_backward(g, feats, loc, w, algo="atomic", dfeats=ref)
+        ref_small.append((dloc, dw))
+    got = [torch.full_like(f, float("nan")) for f in feats]
+    small = []
+    if mode == "deferred":
+        flags = _lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER
+        need = wr.backward_workspace_bytes(feats, loc0, w0, flags)
+        kept = []
+        for loc, w, g in layers:
+            ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+            dloc, dw = torch.full_like(loc, float("nan")), torch.full_like(w, float("nan"))
+            wr.msmv_backward_into(g, feats, loc, w, None, dloc, dw, workspace=ws, flags=flags)
+            kept.append(ws)
+            small.append((dloc, dw))
+        wr.msmv_dfeat_multi([g for _, _, g in layers], kept, feats, Q, P, got)
+    else:
+        for i, (loc, w, g) in enumerate(layers):
+            _, dloc, dw = wr.msmv_backward(g, feats, loc, w, algo="owner", dfeats=got if i else None,
+                                           out_dfeats=None if i else got)
+            small.append((dloc, dw))
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert torch.isfinite(a).all(), f"dfeat{i}: not every element written"
+        assert (a - b).abs().max().item() <= GRAD_RTOL * b.abs().max().item(), f"dfeat{i} [{mode}] vs atomic sum"
+    for (dl, dw), (rl, rw) in zip(small, ref_small):
+        assert (dl - rl).abs().max().item() <= GRAD_RTOL * rl.abs().max().item()
+        assert (dw - rw).abs().max().item() <= GRAD_RTOL * rw.abs().max().item()
+    sl = slice(B - 1, B)
+    f_np = [f[sl].cpu().numpy() for f in feats]
+    total = None
+    for loc, w, g in layers:
+        df, _, _ = oracle.backward(g[sl].cpu().numpy(), f_np, loc[sl].cpu().numpy(), w[sl].cpu().numpy())
+        total = df if total is None else [a + b for a, b in zip(total, df)]
+    for i, d in enumerate(got):
+        assert_close(d[sl].cpu().numpy(), total[i], GRAD_RTOL, f"dfeat{i} last slab, six layers [{mode}]")

@@ -183,3 +183,145 @@ def test_sampling_inputs_follow_the_decoder_module():
     assert torch.allclose(sp[:, :, 0], want, atol=1e-5)
     sp1, _ = opus_sampling.sampling_inputs(qp[:, :, :1], feat, ow, ob, sw_w, sw_b, T, G, P, L, rng)
     assert torch.allclose(sp1[:, :, 0, 0, 0], pts[:, :, 0])
+
+
+def test_workspace_bytes_is_zero_where_the_owner_algorithm_does_not_apply(lib):
+    """More than 16 views exceed the sort's key table: no owner algorithm, hence no workspace
+    (FeatureGradSink reads a non-zero size as 'the owner algorithm applies')."""
+    ws = lib.opus_msmv_backward_workspace_bytes
+    assert ws(4, 32, 64, 16, 100, 2, 0) > 0
+    assert ws(4, 32, 64, 17, 100, 2, 0) == 0
+    assert ws(4, 32, 64, 17, 100, 2, 2) == 0
+    # the d-feat stage alone needs no d loc / d weights (it never writes them): the NULL check
+    # that fires is the one for the data it does read
+    null = ctypes.c_void_p(0)
+    from opus_amd import _lib
+    hw, ptrs = _lib.int_array([4, 4]), _lib.ptr_array([1 << 12])
+    one = ctypes.c_void_p(1 << 12)
+    bwd = lib.opus_msmv_backward
+    # workspace missing is the first complaint once all needed pointers are there
+    assert bwd(1, one, ptrs, hw, one, one, 1, 64, 6, 1, 1, ptrs, null, null, null, 0, 0x202, null) == -7   # L = 1: no owner
+    real = _lib.int_array([64, 176, 32, 88, 16, 44, 8, 22])
+    p4 = _lib.ptr_array([1 << 12] * 4)
+    assert bwd(4, one, p4, real, one, one, 1, 64, 6, 1, 1, p4, null, null, null, 0, 0x202, null) == -6    # d-feat stage: d loc may be NULL
+    assert bwd(4, one, p4, real, one, one, 1, 64, 6, 1, 1, p4, null, null, null, 0, 0x402, null) == -4    # gather stage: it may not
+
+
+_CHILD_ENV = {"OPUS_MSMV_LIB": "/nonexistent/libopus_msmv.so"}
+
+
+def _run_child(code, **env):
+    import subprocess
+    import sys
+    e = dict(os.environ, **_CHILD_ENV, **env)
+    e["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")])
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_dispatcher_without_the_library_raises_by_default():
+    out = _run_child("""
+import torch
+from opus_amd.csrc import wrapper
+assert wrapper.MSMV_CUDA is False
+try:
+    wrapper.msmv_sampling([torch.zeros(1, 1, 1, 2, 2)] * 4, torch.zeros(1, 1, 1, 3), torch.zeros(1, 1, 1, 4))
+except RuntimeError as e:
+    assert 'not loaded' in str(e)
+    print('raised')
+""")
+    assert "Warning: failed to load the HIP extension" in out and "raised" in out
+
+
+def test_dispatcher_fallback_arm_is_the_reference_s(oracle):
+    """OPUS_MSMV_ALLOW_FALLBACK=1 without the library: MSMV_CUDA is False and msmv_sampling is
+    msmv_sampling_pytorch on channel-first features (reference wrapper.py:8-11, :87-93) - checked
+    on the 4- and 5-level fixtures and, through sampling_4d, on the caller fixture."""
+    out = _run_child("""
+import numpy as np, torch
+from helpers import assert_close, golden_feats, load_golden, FWD_RTOL
+from opus_amd.csrc import wrapper
+from opus_amd import opus_sampling
+assert wrapper.MSMV_CUDA is False
+for name in ('g1_tiny4', 'g3_tiny5'):
+    g = load_golden(name)
+    cf = [torch.from_numpy(f).permute(0, 4, 1, 2, 3).contiguous() for f in golden_feats(g)]
+    out = wrapper.msmv_sampling(cf, torch.from_numpy(g['loc']), torch.from_numpy(g['w']))
+    assert_close(out.numpy(), g['out'], 1e-6, name)
+g = load_golden('g5_sampling4d')
+cf = [torch.from_numpy(g[f'feat_cf{i}']) for i in range(4)]
+out = opus_sampling.sampling_4d(torch.from_numpy(g['sample_points']), cf, torch.from_numpy(g['scale_weights']),
+                                torch.from_numpy(g['occ2img']), int(g['image_h']), int(g['image_w']),
+                                int(g['num_views']), fused=False)
+assert_close(out.numpy(), g['out'], FWD_RTOL, 'sampling_4d through the fallback')
+print('fallback ok')
+""", OPUS_MSMV_ALLOW_FALLBACK="1")
+    assert "performance may be hurt" in out and "fallback ok" in out
+
+
+def test_opus_t_batch1_on_cpu_through_the_fallback(oracle):
+    """The plumbing configuration: OPUS-T (Q = 600, P = 4), batch 1, 8 frames x 6 views x 4
+    levels at full size on the CPU - decoder layout prep (channel-first), sampling_4d's
+    projection / packing, msmv_sampling's fallback arm, un-pack - against the C oracle on the
+    same packed locations (first and last slab)."""
+    out = _run_child("""
+import time
+import numpy as np, torch
+from helpers import REAL_LEVELS, FWD_RTOL, assert_close, sampling4d_case
+from opus_amd.csrc import wrapper
+from opus_amd import opus_sampling
+from oracle import msmv_oracle
+assert wrapper.MSMV_CUDA is False
+B, Q, T, G, P, N, C = 1, 600, 8, 4, 4, 6, 64
+pts, sw, occ2img = sampling4d_case(11, B, Q, T, G, P, N=N)
+gen = torch.Generator().manual_seed(3)
+backbone = [torch.randn((B, T * N, G * C, h, w), generator=gen) for h, w in REAL_LEVELS]
+cf = opus_sampling.relayout_features_channel_first(backbone, T, N, G)
+assert cf[0].shape == (B * T * G, C, N, 64, 176)
+t0 = time.perf_counter()
+out = opus_sampling.sampling_4d(torch.from_numpy(pts), cf, torch.from_numpy(sw), torch.from_numpy(occ2img),
+                                256, 704, N, fused=False)
+dt = time.perf_counter() - t0
+assert out.shape == (B, Q, G, T * P, C)
+loc, w = opus_sampling.project_and_pack_torch(torch.from_numpy(pts), torch.from_numpy(sw),
+                                              torch.from_numpy(occ2img), 256, 704, N)
+cl = opus_sampling.relayout_features_torch(backbone, T, N, G)
+packed = out.reshape(B, Q, G, T, P, C).permute(0, 3, 2, 1, 5, 4).reshape(B * T * G, Q, C, P)
+for slab in (0, B * T * G - 1):
+    ref = msmv_oracle.forward([f[slab:slab + 1].numpy() for f in cl], loc[slab:slab + 1].numpy(),
+                              w[slab:slab + 1].numpy())
+    assert_close(packed[slab:slab + 1].numpy(), ref, FWD_RTOL, f'slab {slab}')
+print('opus-t cpu ok: %d points in %.2f s on %d threads' % (B * T * G * Q * P, dt, torch.get_num_threads()))
+""", OPUS_MSMV_ALLOW_FALLBACK="1")
+    assert "opus-t cpu ok" in out
+
+
+def test_feature_grad_sink_is_released_without_a_cyclic_collection():
+    """sink -> token -> grad_fn must not lead back to the sink: dropping the last reference
+    frees it (and its aliases of the feature maps) at once, gc disabled."""
+    import gc
+    import weakref
+    from opus_amd.csrc import wrapper
+    gc.collect()
+    gc.disable()
+    try:
+        feats = [torch.zeros(1, 2, 2, 2, 4, requires_grad=True) for _ in range(4)]
+        sink = wrapper.FeatureGradSink(feats, defer=False)
+        assert sink.token.grad_fn is not None
+        ref = weakref.ref(sink)
+        alias = weakref.ref(sink.feats[0])
+        del sink
+        assert ref() is None and alias() is None
+    finally:
+        gc.enable()
+
+
+def test_feature_grad_sink_notices_in_place_updates():
+    from opus_amd.csrc import wrapper
+    feats = [torch.zeros(1, 2, 2, 2, 4) for _ in range(4)]
+    sink = wrapper.FeatureGradSink(feats, defer=False)
+    sink.check_versions()
+    feats[2].add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        sink.check_versions()
