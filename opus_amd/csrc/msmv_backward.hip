@@ -411,19 +411,28 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
 // most four non-zeros per column), G[h] = the point's 64-channel gradient vector.  Each
 // WAVE owns one patch and keeps D in registers as two 32x32 fp32 MFMA accumulators
 // (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, K = 2 hits per instruction; tile 0 holds
-// the even channels, tile 1 the odd ones, so that a lane fetches its two channels of
-// grad_out with one vector load and stores them with one 8-byte store).  The dense product
-// does 8x the multiply-adds the sparse one needs, but it runs on the otherwise idle matrix
-// pipe: the earlier versions of this kernel, which applied every hit with LDS
-// read-modify-writes, were bound by VALU / scalar / LDS instruction issue (45 CU cycles per
+// channels 0..31, tile 1 channels 32..63, lane = channel within the tile, so that a half-wave
+// stores 128 contiguous bytes of one pixel per instruction straight from an accumulator
+// register, with a wave-uniform base and an immediate offset - no address arithmetic).
+// The dense product does 8x the multiply-adds the sparse one needs, but it runs on the
+// otherwise idle matrix pipe: the earlier versions of this kernel, which applied every hit with
+// LDS read-modify-writes, were bound by VALU / scalar / LDS instruction issue (45 CU cycles per
 // hit), and LDS float atomics (ds_add_f32) cost ~190 LDS cycles per wave instruction.
 // No pixel is shared between waves, nothing is cleared, every d-feat byte is stored once.
 // The patch is 4 rows x 8 columns rather than 32 pixels of one row because a point's 2x2
 // footprint then falls into 1.4 patches on average instead of 2.1: a third fewer hits.
 //
 // A wave scans only the bins whose bands can reach its rows / columns; lanes that find a
-// hit (a point with a corner in the patch) write a 32-byte record into a small per-wave LDS
-// queue; the wave then consumes the queue two records at a time (one per half-wave).
+// hit (a point with a corner in the patch) write a record into a small per-wave LDS queue;
+// the wave then consumes the queue two records at a time (one per half-wave).  The kernel is
+// bound by instruction issue, so the record is laid out for the consumer: bilinear weights are
+// separable, W[pixel (r, c)] = wy[r] * wx[c], and a record holds wy for the patch's 4 rows and
+// wx for its 8 columns as two small zero-filled tables into which the scanning lane drops
+// (hh * w_l, lh * w_l) at the footprint's rows and (hw, lw) at its columns (one guard slot on
+// each side takes what falls outside the patch).  The consuming lane, which stands for one
+// pixel, reads its row's and its column's entry and multiplies: one VALU instruction per pair
+// of hits where four compare / select pairs used to pick the corner that lands on the pixel.
+// Corners outside the image need no test: their rows / columns belong to no stored pixel.
 //
 // A wave applies its hits one after the other and keeps only two groups of gradient loads in
 // flight, so its run time grows with the hits of its patch: a patch of a coarse level (or of a
@@ -449,24 +458,41 @@ constexpr int OWN_THREADS = OWN_WAVES * 64;
 #define MSMV_OWN_SPLIT_HITS_MULTI 256            // the same for a pass over several point sets: per-patch set-up is spread over
 #endif                                           // more hits there (six OPUS-L layers: 64 -> 795 us, 256 -> 764, 1024 -> 768 but 1017 on crowded images)
 constexpr int OWN_QCAP = 16;             // hit records a wave queues before consuming them
-constexpr int OWN_GROUP = 2;             // record pairs per group; two groups' gradient loads are in flight
+
+// A queued hit record, in dwords:
+//   [0] point index (or grad_out row)     [1] point set (MULTI)
+//   [2..7]  wy for patch rows -1..4       (rows 0..3 are real, -1 and 4 are guards)
+//   [8..17] wx for patch columns -1..8    (columns 0..7 are real)
+//   [18..19] padding to a multiple of 16 bytes
+constexpr int REC_DW = 20;
+constexpr int REC_Y0 = 3, REC_X0 = 9;    // dword of row 0 / column 0
+
+// Geometry of one level, packed into 64 bytes so that a wave fetches it with one wave-uniform load
+// once it knows its level.
+struct OwnerLevel {
+    float *dfeat;
+    int H, W;
+    int tiles;                  // workgroups per (batch, view) slab of the level
+    int patch_cols;             // patches per row of patches: ceil(W / PATCH_W)
+    int patches;                // patches per slab: ceil(H / PATCH_H) * patch_cols
+    int split_log2;             // log2 K: waves per patch at the level (K in {1,2,4,8})
+    MsmvDiv div_tiles, div_cols, div_hm1, div_wm1;   // divisors: tiles, patch_cols, H - 1, W - 1
+};
+static_assert(sizeof(OwnerLevel) == 64, "one 64-byte scalar load per level");
 
 struct OwnerGeom {
-    int tiles_per_level[MSMV_MAX_LEVELS];   // workgroups per (batch, view) slab of the level
-    int patch_cols[MSMV_MAX_LEVELS];        // patches per row of patches: ceil(W / PATCH_W)
-    int patches[MSMV_MAX_LEVELS];           // patches per slab: ceil(H / PATCH_H) * patch_cols
-    int split_log2[MSMV_MAX_LEVELS];        // log2 K: waves per patch at the level (K in {1,2,4,8})
-    MsmvDiv div_tiles[MSMV_MAX_LEVELS];     // divisors for the kernel's index arithmetic: tiles_per_level,
-    MsmvDiv div_cols[MSMV_MAX_LEVELS];      // patch_cols,
-    MsmvDiv div_hm1[MSMV_MAX_LEVELS];       // H - 1 and
-    MsmvDiv div_wm1[MSMV_MAX_LEVELS];       // W - 1 of the level,
-    MsmvDiv div_tiles_per_b;                // and tiles_per_b
-    int tiles_per_b;                         // N * sum over levels
+    OwnerLevel lv[MSMV_MAX_LEVELS];
+    // workgroups of a batch slab are ordered [level, coarse first][view][tile]: seg_end[k] is the
+    // end of the k-th level in that order (level L-1-k); INT_MAX from the last level on
+    int seg_end[MSMV_MAX_LEVELS];
+    MsmvDiv div_tiles_per_b;
+    int tiles_per_b;            // N * sum over levels of tiles
+    int L, N, qp, P;
 };
 
 // The sorted point sets one d-feat launch accumulates: normally one (this call's), several when
 // a stack of layers that sample the same feature maps defers its d feats to one pass - d feat
-// is then written once instead of once per layer.  All sets share the sizes in MsmvArgs.
+// is then written once instead of once per layer.  All sets share the sizes in OwnerGeom.
 constexpr int OWN_MAX_SETS = 8;
 struct OwnerSets {
     const float *gout[OWN_MAX_SETS];        // gradient of the op's output, per set
@@ -481,101 +507,63 @@ typedef __attribute__((address_space(3))) void *msmv_lptr_t;
 #ifndef MSMV_OWN_NT_STORE
 #define MSMV_OWN_NT_STORE 1
 #endif
-#ifndef MSMV_OWN_STAGED
-#define MSMV_OWN_STAGED 1
-#endif
 #ifndef MSMV_OWN_STAGE_F4
-#define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave (with the queue 4.5 KiB): LDS never limits the occupancy
+#define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave: with the queue, LDS never limits the occupancy
 #endif
 #ifndef MSMV_OWN_OCC
 #define MSMV_OWN_OCC 4, 8
 #endif
 
-// grad_out of point pt for channels c0 = 2*l32 and c0 + 1.  grad_out is [B,Q,C,P]: for P in
-// {1,2,4} the 2*P floats are contiguous and fetched with 8/16-byte loads (a half-wave reads
-// 256*P contiguous bytes); the generic form is a P-strided dword gather.
-template <int PT>
-struct GradRaw { float v[PT == 0 ? 2 : 2 * PT]; };
-
-template <int PT>
-__device__ __forceinline__ GradRaw<PT> msmv_load_grad(const MsmvArgs &a, const float *gout, int pt, int l32)
-{
-    GradRaw<PT> r;
-    if constexpr (PT == 0) {
-        const int bq = pt / a.P, p = pt - bq * a.P;
-        const float *gp = gout + ((size_t)bq * 64 + l32 * 2) * a.P + p;
-        r.v[0] = gp[0];
-        r.v[1] = gp[(size_t)a.P];
-    } else if constexpr (PT == 1) {
-        const float2 t = *reinterpret_cast<const float2 *>(gout + (size_t)pt * 64 + l32 * 2);
-        r.v[0] = t.x; r.v[1] = t.y;
-    } else if constexpr (PT == 2) {
-        const float4 t = *reinterpret_cast<const float4 *>(gout + ((size_t)(pt >> 1) * 64 + l32 * 2) * 2);
-        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
-    } else {
-        const float4 *gp = reinterpret_cast<const float4 *>(gout + ((size_t)(pt >> 2) * 64 + l32 * 2) * 4);
-        const float4 t = gp[0], u = gp[1];
-        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
-        r.v[4] = u.x; r.v[5] = u.y; r.v[6] = u.z; r.v[7] = u.w;
-    }
-    return r;
-}
-
-template <int PT>
-__device__ __forceinline__ float2 msmv_select_grad(const GradRaw<PT> &r, int pt)
-{
-    if constexpr (PT == 0 || PT == 1) {
-        return make_float2(r.v[0], r.v[1]);
-    } else if constexpr (PT == 2) {
-        // component-wise selects on named values: a select between aggregates by a scalar
-        // makes hipcc spill the array to scratch and index it
-        const float a0 = r.v[0], a1 = r.v[1], b0 = r.v[2], b1 = r.v[3];
-        const bool odd = pt & 1;
-        float2 g;
-        g.x = odd ? a1 : a0;
-        g.y = odd ? b1 : b0;
-        return g;
-    } else {
-        const bool p1 = pt & 1, p2 = pt & 2;
-        const float a0 = r.v[0], a1 = r.v[1], a2 = r.v[2], a3 = r.v[3];
-        const float b0 = r.v[4], b1 = r.v[5], b2 = r.v[6], b3 = r.v[7];
-        float2 g;
-        g.x = p2 ? (p1 ? a3 : a2) : (p1 ? a1 : a0);
-        g.y = p2 ? (p1 ? b3 : b2) : (p1 ? b1 : b0);
-        return g;
-    }
-}
-
-// What one lane knows about the bin entry it scanned (one point against this wave's run).
 // d feat is written once and not read again by this pass: a streaming (non-temporal) store
 // keeps it from displacing the feature maps and gradients that the following kernels read.
-__device__ __forceinline__ void msmv_store_stream(float *p, float x, float y)
+__device__ __forceinline__ void msmv_store_stream(float *p, float x)
 {
 #if MSMV_OWN_NT_STORE
-    typedef float msmv_f32x2 __attribute__((ext_vector_type(2)));
-    msmv_f32x2 v = {x, y};
-    __builtin_nontemporal_store(v, reinterpret_cast<msmv_f32x2 *>(p));
+    __builtin_nontemporal_store(x, p);
 #else
-    *reinterpret_cast<float2 *>(p) = make_float2(x, y);
+    *p = x;
 #endif
 }
 
-__device__ __forceinline__ float2 msmv_load_stream(const float *p)
+__device__ __forceinline__ float msmv_load_stream(const float *p)
 {
 #if MSMV_OWN_NT_STORE
-    typedef float msmv_f32x2 __attribute__((ext_vector_type(2)));
-    const msmv_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const msmv_f32x2 *>(p));
-    return make_float2(v[0], v[1]);
+    return __builtin_nontemporal_load(p);
 #else
-    return *reinterpret_cast<const float2 *>(p);
+    return *p;
 #endif
 }
 
+// Inclusive prefix sum over the first LANES lanes of a wave (LANES = 8: within one DPP row;
+// LANES = 64: the whole wave) with DPP shifts: no LDS round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int msmv_dpp_shift_add(int v)
+{
+    // lanes without a source (and rows outside ROW_MASK) add the `old` operand, 0
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+}
+
+template <int LANES>
+__device__ __forceinline__ int msmv_wave_incl_scan(int v)
+{
+    static_assert(LANES == 8 || LANES == 64, "a quarter row or the wave");
+    v = msmv_dpp_shift_add<0x111, 0xF>(v);      // row_shr:1
+    v = msmv_dpp_shift_add<0x112, 0xF>(v);      // row_shr:2
+    v = msmv_dpp_shift_add<0x114, 0xF>(v);      // row_shr:4
+    if constexpr (LANES == 64) {
+        v = msmv_dpp_shift_add<0x118, 0xF>(v);  // row_shr:8
+        v = msmv_dpp_shift_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+        v = msmv_dpp_shift_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    }
+    return v;
+}
+
+// What one lane knows about the bin entry it scanned (one point against this wave's patch).
 struct OwnHit {
     int pt;
-    bool hit;                        // at least one corner lies in the patch
-    unsigned pix;                    // pixel index inside the patch of corners 1..4, 8 bits each (255 = outside)
-    float cw1, cw2, cw3, cw4;        // corner weight * scale weight (0 for a corner outside the patch)
+    bool hit;                        // the footprint's rows and columns both reach the patch
+    int dr0, dc0;                    // row / column of corner 1 relative to the patch, -1 .. 3 / -1 .. 7 for a hit
+    float y0, y1, x0, x1;            // hh * w_l, lh * w_l, hw, lw
 };
 
 // ACC: add the patch to what d feat already holds instead of overwriting it (one decoder
@@ -588,30 +576,30 @@ struct OwnHit {
 // this needs cost registers, hence occupancy: the single-set kernel is compiled without them.
 template <int PT, bool ACC, bool MULTI>
 __global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(MSMV_OWN_OCC)))
-msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
+msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
 {
-    constexpr int GP = PT == 4 ? 1 : OWN_GROUP;      // P = 4 fetches 32 B per lane and record
-    static_assert(OWN_QCAP % (4 * GP) == 0 && OWN_QCAP <= 64, "queue rounds are consumed in whole groups");
     // STAGED (P in {1,2,4} and row mode): the gradient rows of a whole queue of hits are copied
     // global -> LDS by direct loads (no VGPR destination), all in flight at once, and read from
     // there when the hits are applied.  P-strided rows (other P) are gathered into registers.
-    constexpr bool STAGED = MSMV_OWN_STAGED && PT != 0;
+    constexpr bool STAGED = PT != 0;
     constexpr int ROW_F4 = PT == 4 ? 64 : PT == 2 ? 32 : 16;   // float4 per staged gradient row
     constexpr int STAGE_F4 = MSMV_OWN_STAGE_F4;                // staging area per wave, in float4
     constexpr int QC = STAGED && OWN_QCAP * ROW_F4 > STAGE_F4 ? STAGE_F4 / ROW_F4 : OWN_QCAP;   // records per queue round
-    static_assert(QC * ROW_F4 <= STAGE_F4, "a queue round's rows fit the wave's staging area");
-    __shared__ float4 queue_all[OWN_WAVES][OWN_QCAP * 2];      // 2 float4 per record
+    static_assert(QC * ROW_F4 <= STAGE_F4 || !STAGED, "a queue round's rows fit the wave's staging area");
+    static_assert(QC >= 2 && QC % 2 == 0 && QC <= OWN_QCAP, "records are consumed in pairs");
+    static_assert(REC_DW % 4 == 0, "records are cleared with 16-byte writes");
+    __shared__ float4 queue_all[OWN_WAVES][OWN_QCAP * REC_DW / 4];
     // staging areas; after the hit loop the same memory carries partial tiles between waves
     __shared__ float4 stage_all[OWN_WAVES][STAGE_F4];
     static_assert(sizeof(stage_all) >= (OWN_WAVES / 2) * 32 * 64 * sizeof(float), "partial tiles fit");
-    static_assert(QC >= 2 && QC % 2 == 0, "records are consumed in pairs");
     float (*red)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(&stage_all[0][0]);
 
     const int lane = threadIdx.x & 63;
     const int l32 = lane & 31;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4 *queue = queue_all[wave];
+    float4 *queue4 = queue_all[wave];
+    float *queue = reinterpret_cast<float *>(queue4);
     [[maybe_unused]] float4 *stage = stage_all[wave];
     // MULTI: the sets' gradient arrays, and per wave the concatenation's segment table
     // (entries before the segment, address of its first entry)
@@ -637,41 +625,45 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
     const int b = (int)msmv_div((uint32_t)id, geo.div_tiles_per_b);
     id -= b * geo.tiles_per_b;
-    int l = a.L - 1;
-    for (; l > 0; --l) {
-        const int n = geo.tiles_per_level[l] * a.N;
-        if (id < n)
-            break;
-        id -= n;
+    int k = 0, seg_start = 0;
+#pragma unroll
+    for (int j = 0; j < MSMV_MAX_LEVELS - 1; ++j) {          // (seg_end is INT_MAX from the last level on)
+        const bool past = id >= geo.seg_end[j];
+        k = past ? j + 1 : k;
+        seg_start = past ? geo.seg_end[j] : seg_start;
     }
-    const int view = (int)msmv_div((uint32_t)id, geo.div_tiles[l]);
-    const int tile_idx = id - view * geo.tiles_per_level[l];
-    const int klog = geo.split_log2[l];
+    const int l = geo.L - 1 - k;
+    id -= seg_start;
+    const OwnerLevel G = geo.lv[l];
+    const int N = geo.N;
+    const int view = (int)msmv_div((uint32_t)id, G.div_tiles);
+    const int tile_idx = id - view * G.tiles;
+    const int klog = G.split_log2;
     const int K = 1 << klog;                                 // waves sharing a patch
     const int sub = wave & (K - 1);                          // this wave's share: entries sub, sub + K, ...
     const int patch_raw = tile_idx * (OWN_WAVES >> klog) + (wave >> klog);
-    const bool idle = patch_raw >= geo.patches[l];           // past the slab's last patch: takes part in
+    const bool idle = patch_raw >= G.patches;                // past the slab's last patch: takes part in
     const int patch = idle ? 0 : patch_raw;                  // the barriers below, stores nothing
-    const int H = a.lvl[l].H, W = a.lvl[l].W;
+    const int H = G.H, W = G.W;
     const int S = H * W;
-    const int prow = (int)msmv_div((uint32_t)patch, geo.div_cols[l]);
-    const int r0 = prow * PATCH_H, c0 = (patch - prow * geo.patch_cols[l]) * PATCH_W;
+    const int prow = (int)msmv_div((uint32_t)patch, G.div_cols);
+    const int r0 = prow * PATCH_H, c0 = (patch - prow * G.patch_cols) * PATCH_W;
     const int nrow = min(PATCH_H, H - r0), ncol = min(PATCH_W, W - c0);
 
-    msmv_f32x16 acc0 = {}, acc1 = {};                        // even / odd channels
+    msmv_f32x16 acc0 = {}, acc1 = {};                        // channels 0..31 / 32..63
     [[maybe_unused]] bool any_hit = false;
     [[maybe_unused]] bool touched = false;                   // ACC: pixel l32 of this half's records got a weight
 
     // ---- the bins that can reach this patch: one segment of the sorted entries per y-band
     // (all of them adjacent, i.e. one segment, when every x-band is wanted)
     int yb_lo, yb_hi, xb_lo, xb_hi;
-    msmv_band_range<BIN_YB>(r0, r0 + nrow - 1, H, geo.div_hm1[l], yb_lo, yb_hi);
-    msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, geo.div_wm1[l], xb_lo, xb_hi);
+    msmv_band_range<BIN_YB>(r0, r0 + nrow - 1, H, G.div_hm1, yb_lo, yb_hi);
+    msmv_band_range<BIN_XB>(c0, c0 + ncol - 1, W, G.div_wm1, xb_lo, xb_hi);
     const bool all_x = xb_lo == 0 && xb_hi == BIN_XB - 1;
     const int nseg = all_x ? 1 : yb_hi - yb_lo + 1;          // <= BIN_YB
     [[maybe_unused]] const float *gout = sets.gout[0];
-    const size_t off_slab = (size_t)b * (a.N * BIN_PER_VIEW + 1) + view * BIN_PER_VIEW;
-    [[maybe_unused]] const float4 *list = reinterpret_cast<const float4 *>(sets.entries[0] + (size_t)b * a.qp);
+    const size_t off_slab = (size_t)b * (N * BIN_PER_VIEW + 1) + view * BIN_PER_VIEW;
+    [[maybe_unused]] const float4 *list = reinterpret_cast<const float4 *>(sets.entries[0] + (size_t)b * geo.qp);
 
     // Lane s holds segment s (MULTI: segment s % BIN_YB of set s / BIN_YB): its length, the
     // count of entries before it (excl) and delta = begin - excl, so that virtual entry v of
@@ -692,7 +684,7 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
             const int k_hi = all_x ? (yb_hi + 1) * BIN_XB : (yb_lo + sseg) * BIN_XB + xb_hi + 1;
             seg_begin = offp[off_slab + k_lo];
             seg_len = offp[off_slab + k_hi] - seg_begin;
-            seg_addr = reinterpret_cast<unsigned long long>(entp + (size_t)b * a.qp + seg_begin);
+            seg_addr = reinterpret_cast<unsigned long long>(entp + (size_t)b * geo.qp + seg_begin);
         }
     } else if (lane < nseg) {
         const int *off = sets.offsets[0] + off_slab;
@@ -701,13 +693,8 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
         seg_begin = off[k_lo];
         seg_len = off[k_hi] - seg_begin;
     }
-    int incl = seg_len;
-#pragma unroll
-    for (int d = 1; d < (MULTI ? 64 : BIN_YB); d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if (lane >= d)
-            incl += up;
-    }
+    static_assert(BIN_YB <= 8, "the single-set prefix runs over 8 lanes");
+    const int incl = msmv_wave_incl_scan<MULTI ? 64 : 8>(seg_len);
     const int seg_excl = incl - seg_len;
     [[maybe_unused]] const int seg_delta = seg_begin - seg_excl;
     const int total = idle ? 0 : __builtin_amdgcn_readlane(incl, MULTI ? 63 : nseg - 1);
@@ -753,29 +740,35 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
             wl = reinterpret_cast<const float *>(list + (size_t)ref * 2)[3 + l];
         }
     };
+    const float fHm1 = (float)(H - 1), fWm1 = (float)(W - 1), fH = (float)H, fW = (float)W;
     auto scan = [&](int j0, const float4 &e0, float wl) {
         OwnHit h;
         const bool valid = ((j0 + lane) << klog) + sub < total;
         h.pt = __float_as_int(e0.x);
-        const MsmvTap t = msmv_make_tap(e0.y, e0.z, H, W, valid);
-        // corner rows / columns relative to the patch; the unsigned compares also reject the
-        // -1 row / column of a corner that is off the image (its c-flag is false anyway)
-        const unsigned dr0 = (unsigned)(t.h_low - r0), dr1 = (unsigned)(t.h_low + 1 - r0);
-        const unsigned dc0 = (unsigned)(t.w_low - c0), dc1 = (unsigned)(t.w_low + 1 - c0);
-        const bool rt = dr0 < (unsigned)nrow, rb = dr1 < (unsigned)nrow;
-        const bool cl = dc0 < (unsigned)ncol, cr = dc1 < (unsigned)ncol;
-        const bool in1 = t.c1 && rt && cl, in2 = t.c2 && rt && cr;
-        const bool in3 = t.c3 && rb && cl, in4 = t.c4 && rb && cr;
-        h.hit = in1 || in2 || in3 || in4;
-        const unsigned p1 = in1 ? dr0 * PATCH_W + dc0 : 255u, p2 = in2 ? dr0 * PATCH_W + dc1 : 255u;
-        const unsigned p3 = in3 ? dr1 * PATCH_W + dc0 : 255u, p4 = in4 ? dr1 * PATCH_W + dc1 : 255u;
-        h.pix = p1 | (p2 << 8) | (p3 << 16) | (p4 << 24);
-        h.cw1 = in1 ? t.w1 * wl : 0.f;
-        h.cw2 = in2 ? t.w2 * wl : 0.f;
-        h.cw3 = in3 ? t.w3 * wl : 0.f;
-        h.cw4 = in4 ? t.w4 * wl : 0.f;
+        // the tap's arithmetic (msmv_make_tap): pixel coordinates, range test, floor, fractions
+        float h_im = e0.z * fHm1, w_im = e0.y * fWm1;
+        const bool ok = valid && (h_im > -1.f) && (w_im > -1.f) && (h_im < fH) && (w_im < fW);
+        h_im = ok ? h_im : 0.f;
+        w_im = ok ? w_im : 0.f;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const float lh = h_im - hf, lw = w_im - wf;
+        h.dr0 = (int)hf - r0;
+        h.dc0 = (int)wf - c0;
+        // rows dr0, dr0 + 1 and columns dc0, dc0 + 1 against the patch's nrow x ncol pixels.  A
+        // corner that is off the image (row -1 or H, column -1 or W) lies on no pixel that is
+        // stored, so per-corner zero padding needs no test here.
+        h.hit = ok && (unsigned)(h.dr0 + 1) <= (unsigned)nrow && (unsigned)(h.dc0 + 1) <= (unsigned)ncol;
+        h.y0 = (1.f - lh) * wl;
+        h.y1 = lh * wl;
+        h.x0 = 1.f - lw;
+        h.x1 = lw;
         return h;
     };
+
+    // lane-constant pieces of the queue reads: record `half` of a pair, this pixel's row / column
+    const float *q_wy = queue + half * REC_DW + REC_Y0 + (l32 >> 3);
+    const float *q_wx = queue + half * REC_DW + REC_X0 + (l32 & 7);
+    const float *q_pt = queue + half * REC_DW;
 
 #ifdef MSMV_ABL_NOSCAN
     if (false)
@@ -787,13 +780,13 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
         load_entry(entry_index(0), e0, wl, eset);
         for (int j0 = 0; (j0 << klog) + sub < total; j0 += 64) {
             const OwnHit h = scan(j0, e0, wl);
-            [[maybe_unused]] const float hset = __int_as_float(eset);   // rides in the record's spare slot
+            [[maybe_unused]] const float hset = __int_as_float(eset);
             if (((j0 + 64) << klog) + sub < total)             // next chunk's entries, in flight
                 load_entry(entry_index(j0 + 64), e0, wl, eset);     // while this chunk's hits are applied
 
             unsigned long long hits = __ballot(h.hit);
 #ifdef MSMV_ABL_NOHITS
-            asm volatile("" ::"v"(h.pix), "v"(h.cw1), "v"(h.cw2), "v"(h.cw3), "v"(h.cw4));
+            asm volatile("" ::"v"(h.dr0), "v"(h.dc0), "v"(h.y0), "v"(h.y1), "v"(h.x0), "v"(h.x1));
             hits = 0;
 #endif
             const int nh = __popcll(hits);
@@ -802,34 +795,39 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
             for (int qbase = 0; qbase < nh; qbase += QC) {
-                // every slot first gets a null record (a valid point, all weights 0), then
-                // hit lanes qbase .. qbase+QC-1 (in lane order) overwrite theirs: the queue
-                // can then be consumed in whole groups without branches around the loads
+                // every slot first becomes a null record (a valid point, all weights 0), then
+                // hit lanes qbase .. qbase+QC-1 (in lane order) fill theirs in: the queue can
+                // then be consumed in whole pairs without branches around the loads
                 if (lane < QC) {
-                    queue[lane * 2] = make_float4(__int_as_float(h.pt), 0.f, 0.f, 0.f);
-                    queue[lane * 2 + 1] = make_float4(0.f, __uint_as_float(0xFFFFFFFFu), MULTI ? hset : 0.f, 0.f);
+                    typedef float rec_f32x4 __attribute__((ext_vector_type(4)));
+                    rec_f32x4 *rec = reinterpret_cast<rec_f32x4 *>(queue4 + lane * (REC_DW / 4));
+                    const rec_f32x4 head = {__int_as_float(h.pt), MULTI ? hset : 0.f, 0.f, 0.f};
+                    const rec_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    rec[0] = head;
+#pragma unroll
+                    for (int i = 1; i < REC_DW / 4; ++i)
+                        rec[i] = zero;
                 }
                 const unsigned slot = (unsigned)(rank - qbase);
                 if (h.hit && slot < (unsigned)QC) {
-                    queue[slot * 2] = make_float4(__int_as_float(h.pt), h.cw1, h.cw2, h.cw3);
-                    queue[slot * 2 + 1] = make_float4(h.cw4, __uint_as_float(h.pix), MULTI ? hset : 0.f, 0.f);
+                    float *rec = queue + slot * REC_DW;
+                    rec[0] = __int_as_float(h.pt);
+                    rec[1] = MULTI ? hset : 0.f;
+                    rec[REC_Y0 + h.dr0] = h.y0;
+                    rec[REC_Y0 + 1 + h.dr0] = h.y1;
+                    rec[REC_X0 + h.dc0] = h.x0;
+                    rec[REC_X0 + 1 + h.dc0] = h.x1;
                 }
                 const int cnt = min(QC, nh - qbase);
+                const int npairs = (cnt + 1) >> 1;
 
 #ifdef MSMV_ABL_NORMW
-#define MSMV_OWN_MFMA(WA, GU) asm volatile("" ::"v"(WA), "v"(GU.x), "v"(GU.y));
+#define MSMV_OWN_MFMA(WA, G0, G1) asm volatile("" ::"v"(WA), "v"(G0), "v"(G1));
 #else
-#define MSMV_OWN_MFMA(WA, GU)                                                                 \
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, GU.x, acc0, 0, 0, 0);     \
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, GU.y, acc1, 0, 0, 0);
+#define MSMV_OWN_MFMA(WA, G0, G1)                                                             \
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, G0, acc0, 0, 0, 0);       \
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, G1, acc1, 0, 0, 0);
 #endif
-                /* column of W for this half's record: the weight whose corner is pixel l32 */
-#define MSMV_OWN_WCOL(WA, RK, RO)                                                             \
-                    const unsigned pix = __float_as_uint(RO.y);                               \
-                    float WA = (pix >> 24) == (unsigned)l32 ? RO.x : 0.f;                     \
-                    WA = ((pix >> 16) & 255u) == (unsigned)l32 ? RK.w : WA;                   \
-                    WA = ((pix >> 8) & 255u) == (unsigned)l32 ? RK.z : WA;                    \
-                    WA = (pix & 255u) == (unsigned)l32 ? RK.y : WA;
 
                 if constexpr (STAGED) {
                     // ---- all rows of the round: global -> LDS, 1 KiB per wave instruction
@@ -839,15 +837,14 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
                     // is a null record (weights 0), and its row must be loaded too - 0 times
                     // whatever an earlier kernel left in LDS can be NaN
                     const int ninstr = (cnt + (cnt & 1) + RPI - 1) / RPI;
-                    const float *qf = reinterpret_cast<const float *>(queue);
                     int rpt[MAXI];
                     const float *rgo[MAXI];
 #pragma unroll
                     for (int i = 0; i < MAXI; ++i) {                   // the record this lane copies a piece of
-                        rpt[i] = __float_as_int(qf[(i * RPI + lane / ROW_F4) * 8]);
+                        rpt[i] = __float_as_int(queue[(i * RPI + lane / ROW_F4) * REC_DW]);
                         rgo[i] = gout;
                         if constexpr (MULTI)
-                            rgo[i] = gout_tab[__float_as_int(qf[(i * RPI + lane / ROW_F4) * 8 + 6])];
+                            rgo[i] = gout_tab[__float_as_int(queue[(i * RPI + lane / ROW_F4) * REC_DW + 1])];
                     }
 #pragma unroll
                     for (int i = 0; i < MAXI; ++i) {
@@ -857,82 +854,77 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
                             __builtin_amdgcn_global_load_lds((msmv_gptr_t)src, (msmv_lptr_t)(stage + i * 64), 16, 0, 0);
                         }
                     }
-                    // ---- apply: half-wave `half` takes record 2*pair + half; the next pair's
-                    // record is fetched from the queue while this pair's product runs
-                    const int npairs = (cnt + 1) >> 1;
-                    float4 rk = queue[half * 2], ro = queue[half * 2 + 1];
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    for (int u = 0; u < npairs; ++u) {
-                        const int r = u * 2 + half;
-                        const float *sp = reinterpret_cast<const float *>(stage + r * ROW_F4);
-                        float2 gu;
-                        if constexpr (PT == 1) {
-                            gu = *reinterpret_cast<const float2 *>(sp + l32 * 2);
-                        } else {
-                            const int p = __float_as_int(rk.x) & (PT - 1);
-                            gu.x = sp[l32 * 2 * PT + p];
-                            gu.y = sp[l32 * 2 * PT + PT + p];
-                        }
-                        const int rn = min(r + 2, QC - 2 + half);      // (the queue's last pair, at worst a null record)
-                        const float4 rk_n = queue[rn * 2], ro_n = queue[rn * 2 + 1];
-                        MSMV_OWN_WCOL(wa, rk, ro)
-                        MSMV_OWN_MFMA(wa, gu)
-                        if constexpr (ACC)
-                            touched = touched || wa != 0.f;
-                        rk = rk_n;
-                        ro = ro_n;
+                    // ---- apply: half-wave `half` takes record 2*pair + half.  Fully unrolled, so
+                    // that every LDS address is a lane constant plus an immediate.  The weights of
+                    // all pairs (null records included: their tables are zero) are fetched from the
+                    // queue while the rows are still on their way; the rows are then read one pair
+                    // ahead of the product that uses them.
+                    constexpr int NP = QC / 2;
+                    float wa[NP];
+                    [[maybe_unused]] int poff[NP];
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        wa[u] = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
+                        if constexpr (PT != 1)
+                            poff[u] = __float_as_int(q_pt[u * 2 * REC_DW]) & (PT - 1);
                     }
-                    // the next round's copies must not overtake this round's LDS reads
+                    const float *sp0 = reinterpret_cast<const float *>(stage + half * ROW_F4) + l32 * (PT == 1 ? 1 : PT);
+                    auto row_read = [&](int u, float &g0, float &g1) {
+                        const float *sp = sp0 + u * 2 * ROW_F4 * 4;
+                        if constexpr (PT == 1) {
+                            g0 = sp[0];
+                            g1 = sp[32];
+                        } else {
+                            g0 = sp[poff[u]];
+                            g1 = sp[32 * PT + poff[u]];
+                        }
+                    };
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    float g0, g1;
+                    row_read(0, g0, g1);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        if (u < npairs) {                              // wave-uniform
+                            float n0 = 0.f, n1 = 0.f;
+                            if (u + 1 < NP)
+                                row_read(u + 1, n0, n1);               // (stale but harmless when pair u + 1 does not exist)
+                            MSMV_OWN_MFMA(wa[u], g0, g1)
+                            if constexpr (ACC)
+                                touched = touched || wa[u] != 0.f;
+                            g0 = n0;
+                            g1 = n1;
+                        }
+                    }
+                    // the next round's copies and queue writes must not overtake this round's LDS reads
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
-                const int ngroups = (cnt + 2 * GP - 1) / (2 * GP);
-
-                // Half-wave `half` takes record 2*pair + half.  Two register sets (A, B) hold
-                // one group of GP pairs each; the loads of group g+1 are issued before group g
-                // is applied, and every path is straight-line so that the compiler's counted
-                // waits leave them in flight.  Only the point index and the gradient values are
-                // carried; weights and pixel indices are re-read from the queue when applied.
-                int a_pt[GP], b_pt[GP];
-                GradRaw<PT> a_g[GP], b_g[GP];
-#define MSMV_OWN_LOAD(X, G)                                                                   \
-                _Pragma("unroll") for (int u = 0; u < GP; ++u) {                             \
-                    const float *q = reinterpret_cast<const float *>(queue + (((G) * GP + u) * 2 + half) * 2); \
-                    X##_pt[u] = __float_as_int(q[0]);                                         \
-                    X##_g[u] = msmv_load_grad<PT>(a, MULTI ? gout_tab[__float_as_int(q[6])] : gout, X##_pt[u], l32); \
-                }
-#define MSMV_OWN_APPLY(X, G)                                                                  \
-                _Pragma("unroll") for (int u = 0; u < GP; ++u) {                             \
-                    const float4 rk = queue[(((G) * GP + u) * 2 + half) * 2];                \
-                    const float4 ro = queue[(((G) * GP + u) * 2 + half) * 2 + 1];            \
-                    const float2 gu = msmv_select_grad<PT>(X##_g[u], X##_pt[u]);             \
-                    MSMV_OWN_WCOL(wa, rk, ro)                                                 \
-                    MSMV_OWN_MFMA(wa, gu)                                                     \
-                    if constexpr (ACC)                                                        \
-                        touched = touched || wa != 0.f;                                       \
-                }
-                MSMV_OWN_LOAD(a, 0)
-                for (int g = 0;;) {
-                    if (g + 1 < ngroups) {
-                        MSMV_OWN_LOAD(b, g + 1)
-                        MSMV_OWN_APPLY(a, g)
-                    } else {
-                        MSMV_OWN_APPLY(a, g)
-                        break;
+                    // P-strided gradient rows: channels l32 and l32 + 32 of the record's point, gathered
+                    // into registers one pair ahead of their use
+                    auto fetch = [&](int u, float &g0, float &g1) {
+                        const int pt = __float_as_int(q_pt[u * 2 * REC_DW]);
+                        const float *go = gout;
+                        if constexpr (MULTI)
+                            go = gout_tab[__float_as_int(q_pt[u * 2 * REC_DW + 1])];
+                        const int bq = pt / geo.P, p = pt - bq * geo.P;
+                        const float *gp = go + ((size_t)bq * 64 + l32) * geo.P + p;
+                        g0 = gp[0];
+                        g1 = gp[(size_t)32 * geo.P];
+                    };
+                    float g0, g1;
+                    fetch(0, g0, g1);
+                    for (int u = 0; u < npairs; ++u) {
+                        float n0 = 0.f, n1 = 0.f;
+                        if (u + 1 < npairs)                            // wave-uniform
+                            fetch(u + 1, n0, n1);
+                        const float wa = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
+                        MSMV_OWN_MFMA(wa, g0, g1)
+                        if constexpr (ACC)
+                            touched = touched || wa != 0.f;
+                        g0 = n0;
+                        g1 = n1;
                     }
-                    ++g;
-                    if (g + 1 < ngroups) {
-                        MSMV_OWN_LOAD(a, g + 1)
-                        MSMV_OWN_APPLY(b, g)
-                    } else {
-                        MSMV_OWN_APPLY(b, g)
-                        break;
-                    }
-                    ++g;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-#undef MSMV_OWN_LOAD
-#undef MSMV_OWN_APPLY
-                }
-#undef MSMV_OWN_WCOL
 #undef MSMV_OWN_MFMA
             }
         }
@@ -971,11 +963,12 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
     }
 
     // ---- store the patch once.  Accumulator register r of lane (half, l32) is patch pixel
-    // i = (r & 3) + 8 * (r >> 2) + 4 * half, i.e. row i / PATCH_W, column i % PATCH_W, channels
-    // 2*l32 (tile 0) and 2*l32 + 1 (tile 1): each half-wave stores one whole 256-byte pixel
-    // per instruction.  (Exchanging registers between lane pairs to issue 16-byte stores
-    // instead measured 7 % slower: the two pixels then interleave lane by lane.)
-    float *dst = a.lvl[l].dfeat + (((size_t)b * a.N + view) * (size_t)S + (size_t)r0 * W + c0) * 64 + l32 * 2;
+    // i = (r & 3) + 8 * (r >> 2) + 4 * half, i.e. row r >> 2, column (r & 3) + 4 * half, channel
+    // l32 (tile 0) or 32 + l32 (tile 1): each half-wave stores 128 contiguous bytes of one pixel
+    // per instruction.  The row base is wave-uniform, the lane's part (its channel and the
+    // half-wave's 4 columns) is one register for all 32 stores, the rest an immediate.
+    float *dst = G.dfeat + (((size_t)b * N + view) * (size_t)S + (size_t)r0 * W + c0) * 64;
+    const unsigned voff = (unsigned)(half * 4 * 64 + l32);
 #ifdef MSMV_ABL_NOSTORE
     if (nrow < 0)
 #endif
@@ -993,39 +986,50 @@ msmv_bwd_owner_dfeat(const MsmvArgs a, OwnerSets sets, OwnerGeom geo)
         // and stores; two batches keep the kernel's register count that of its main loop
 #pragma unroll
         for (int r0b = 0; r0b < 16; r0b += 8) {
-            float2 old[8];
+            float old0[8], old1[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = r0b + k;
+            for (int kk = 0; kk < 8; ++kk) {
+                const int r = r0b + kk;
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int pr = i / PATCH_W, pc = i % PATCH_W;
+                const int pr = r >> 2, pc = (r & 3) + 4 * half;
                 const bool in = pr < nrow && pc < ncol && ((pixels >> i) & 1u);
-                old[k] = msmv_load_stream(dst + (in ? ((size_t)pr * W + pc) * 64 : 0));
+                const float *src = dst + (in ? ((size_t)pr * W + pc) * 64 : 0) + l32;
+                old0[kk] = msmv_load_stream(src);
+                old1[kk] = msmv_load_stream(src + 32);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = r0b + k;
+            for (int kk = 0; kk < 8; ++kk) {
+                const int r = r0b + kk;
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int pr = i / PATCH_W, pc = i % PATCH_W;
-                if (pr < nrow && pc < ncol && ((pixels >> i) & 1u))
-                    msmv_store_stream(dst + ((size_t)pr * W + pc) * 64, old[k].x + acc0[r], old[k].y + acc1[r]);
+                const int pr = r >> 2, pc = (r & 3) + 4 * half;
+                if (pr < nrow && pc < ncol && ((pixels >> i) & 1u)) {
+                    float *o = dst + ((size_t)pr * W + pc) * 64 + l32;
+                    msmv_store_stream(o, old0[kk] + acc0[r]);
+                    msmv_store_stream(o + 32, old1[kk] + acc1[r]);
+                }
             }
         }
     } else if (nrow == PATCH_H && ncol == PATCH_W) {
         // a whole patch (all but the last row / column of patches): no per-pixel tests
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int pr = i / PATCH_W, pc = i % PATCH_W;
-            msmv_store_stream(dst + ((size_t)pr * W + pc) * 64, acc0[r], acc1[r]);
+        for (int pr = 0; pr < PATCH_H; ++pr) {
+            float *rowp = dst + (size_t)pr * W * 64;         // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = pr * 4 + q;
+                msmv_store_stream(rowp + (voff + q * 64), acc0[r]);
+                msmv_store_stream(rowp + (voff + q * 64 + 32), acc1[r]);
+            }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int pr = i / PATCH_W, pc = i % PATCH_W;
-            if (pr < nrow && pc < ncol)
-                msmv_store_stream(dst + ((size_t)pr * W + pc) * 64, acc0[r], acc1[r]);
+            const int pr = r >> 2, pc = (r & 3) + 4 * half;
+            if (pr < nrow && pc < ncol) {
+                float *o = dst + ((size_t)pr * W + pc) * 64 + l32;
+                msmv_store_stream(o, acc0[r]);
+                msmv_store_stream(o + 32, acc1[r]);
+            }
         }
     }
 }
@@ -1261,14 +1265,13 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
 }
 
 template <bool ACC, bool MULTI>
-static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const MsmvArgs &a,
-                               const OwnerSets &sets, const OwnerGeom &geo)
+static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const OwnerGeom &geo, const OwnerSets &sets)
 {
     switch (pt) {
-    case 1: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
-    case 2: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
-    case 4: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<4, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
-    default: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<0, ACC, MULTI>), grid, block, 0, s, a, sets, geo); break;
+    case 1: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, ACC, MULTI>), grid, block, 0, s, geo, sets); break;
+    case 2: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, ACC, MULTI>), grid, block, 0, s, geo, sets); break;
+    case 4: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<4, ACC, MULTI>), grid, block, 0, s, geo, sets); break;
+    default: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<0, ACC, MULTI>), grid, block, 0, s, geo, sets); break;
     }
 }
 
@@ -1288,24 +1291,39 @@ static OwnerWs owner_ws_of(const MsmvArgs &a, void *workspace)
 static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hipStream_t s, bool accumulate)
 {
     OwnerGeom geo = {};
+    geo.L = a.L; geo.N = a.N; geo.qp = a.qp; geo.P = a.P;
     int per_view = 0;
     for (int l = 0; l < a.L; ++l) {
-        geo.patch_cols[l] = (a.lvl[l].W + PATCH_W - 1) / PATCH_W;
-        geo.patches[l] = ((a.lvl[l].H + PATCH_H - 1) / PATCH_H) * geo.patch_cols[l];
+        OwnerLevel &g = geo.lv[l];
+        g.dfeat = a.lvl[l].dfeat;
+        g.H = a.lvl[l].H;
+        g.W = a.lvl[l].W;
+        g.patch_cols = (g.W + PATCH_W - 1) / PATCH_W;
+        g.patches = ((g.H + PATCH_H - 1) / PATCH_H) * g.patch_cols;
         // a point touches ~1.4 patches of a level: expected hits per patch, uniform points
-        const double expect = 1.4 * (double)a.qp * sets.n / ((double)a.N * geo.patches[l]);
+        const double expect = 1.4 * (double)a.qp * sets.n / ((double)a.N * g.patches);
         int klog = 0;
         const double split_hits = sets.n > 1 ? MSMV_OWN_SPLIT_HITS_MULTI : MSMV_OWN_SPLIT_HITS;
         while ((2 << klog) <= OWN_WAVES && expect > split_hits * (1 << klog))
             ++klog;
-        geo.split_log2[l] = klog;
+        g.split_log2 = klog;
         const int per_wg = OWN_WAVES >> klog;
-        geo.tiles_per_level[l] = (geo.patches[l] + per_wg - 1) / per_wg;
-        geo.div_tiles[l] = msmv_make_div(geo.tiles_per_level[l]);
-        geo.div_cols[l] = msmv_make_div(geo.patch_cols[l]);
-        geo.div_hm1[l] = msmv_make_div(a.lvl[l].H - 1);
-        geo.div_wm1[l] = msmv_make_div(a.lvl[l].W - 1);
-        per_view += geo.tiles_per_level[l];
+        g.tiles = (g.patches + per_wg - 1) / per_wg;
+        g.div_tiles = msmv_make_div(g.tiles);
+        g.div_cols = msmv_make_div(g.patch_cols);
+        g.div_hm1 = msmv_make_div(g.H - 1);
+        g.div_wm1 = msmv_make_div(g.W - 1);
+        per_view += g.tiles;
+    }
+    // workgroup order within a batch slab: coarse level first
+    long long end = 0;
+    for (int k = 0; k < MSMV_MAX_LEVELS; ++k) {
+        if (k < a.L - 1) {
+            end += (long long)geo.lv[a.L - 1 - k].tiles * a.N;
+            geo.seg_end[k] = (int)end;
+        } else {
+            geo.seg_end[k] = 0x7FFFFFFF;
+        }
     }
     geo.tiles_per_b = per_view * a.N;
     geo.div_tiles_per_b = msmv_make_div(geo.tiles_per_b);
@@ -1316,13 +1334,13 @@ static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hi
         const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
         const int pt = a.rows ? 1 : a.P;
         if (sets.n > 1 && accumulate)
-            launch_owner_dfeat<true, true>(pt, grid, block, s, a, sets, geo);
+            launch_owner_dfeat<true, true>(pt, grid, block, s, geo, sets);
         else if (sets.n > 1)
-            launch_owner_dfeat<false, true>(pt, grid, block, s, a, sets, geo);
+            launch_owner_dfeat<false, true>(pt, grid, block, s, geo, sets);
         else if (accumulate)
-            launch_owner_dfeat<true, false>(pt, grid, block, s, a, sets, geo);
+            launch_owner_dfeat<true, false>(pt, grid, block, s, geo, sets);
         else
-            launch_owner_dfeat<false, false>(pt, grid, block, s, a, sets, geo);
+            launch_owner_dfeat<false, false>(pt, grid, block, s, geo, sets);
     }
     return hipSuccess;
 }
