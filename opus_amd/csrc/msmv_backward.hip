@@ -574,18 +574,29 @@ struct OwnHit {
 // patch still costs one chain of dependent loads (offsets -> entries -> gradient rows) and not
 // one per set; a hit record carries its set, which selects the gradient array.  The tables
 // this needs cost registers, hence occupancy: the single-set kernel is compiled without them.
+#ifdef MSMV_DBG_TIMES
+// development aid: per-wave phase timestamps (100 MHz constant clock) of the d-feat kernel
+__device__ unsigned long long *msmv_dbg_buf;
+#define MSMV_DBG_STAMP(K) if (lane == 0) dbg_t[K] = __builtin_amdgcn_s_memrealtime();
+#else
+#define MSMV_DBG_STAMP(K)
+#endif
+
 template <int PT, bool ACC, bool MULTI>
 __global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(MSMV_OWN_OCC)))
 msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
 {
+#ifdef MSMV_DBG_TIMES
+    unsigned long long dbg_t[6] = {};
+    dbg_t[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     // STAGED (P in {1,2,4} and row mode): the gradient rows of a whole queue of hits are copied
     // global -> LDS by direct loads (no VGPR destination), all in flight at once, and read from
     // there when the hits are applied.  P-strided rows (other P) are gathered into registers.
     constexpr bool STAGED = PT != 0;
     constexpr int ROW_F4 = PT == 4 ? 64 : PT == 2 ? 32 : 16;   // float4 per staged gradient row
     constexpr int STAGE_F4 = MSMV_OWN_STAGE_F4;                // staging area per wave, in float4
-    constexpr int QC = STAGED && OWN_QCAP * ROW_F4 > STAGE_F4 ? STAGE_F4 / ROW_F4 : OWN_QCAP;   // records per queue round
-    static_assert(QC * ROW_F4 <= STAGE_F4 || !STAGED, "a queue round's rows fit the wave's staging area");
+    constexpr int QC = OWN_QCAP;                               // records per queue round
     static_assert(QC >= 2 && QC % 2 == 0 && QC <= OWN_QCAP, "records are consumed in pairs");
     static_assert(REC_DW % 4 == 0, "records are cleared with 16-byte writes");
     __shared__ float4 queue_all[OWN_WAVES][OWN_QCAP * REC_DW / 4];
@@ -698,6 +709,7 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
     const int seg_excl = incl - seg_len;
     [[maybe_unused]] const int seg_delta = seg_begin - seg_excl;
     const int total = idle ? 0 : __builtin_amdgcn_readlane(incl, MULTI ? 63 : nseg - 1);
+    MSMV_DBG_STAMP(1)
     if constexpr (MULTI) {
         excl_tab[lane] = seg_excl;          // non-decreasing; lanes past the last segment hold `total`
         addr_tab[lane] = seg_addr;
@@ -778,6 +790,10 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         float wl;
         [[maybe_unused]] int eset = 0;
         load_entry(entry_index(0), e0, wl, eset);
+#ifdef MSMV_DBG_TIMES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MSMV_DBG_STAMP(2)
+#endif
         for (int j0 = 0; (j0 << klog) + sub < total; j0 += 64) {
             const OwnHit h = scan(j0, e0, wl);
             [[maybe_unused]] const float hset = __int_as_float(eset);
@@ -819,7 +835,7 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
                     rec[REC_X0 + 1 + h.dc0] = h.x1;
                 }
                 const int cnt = min(QC, nh - qbase);
-                const int npairs = (cnt + 1) >> 1;
+                [[maybe_unused]] const int npairs = (cnt + 1) >> 1;
 
 #ifdef MSMV_ABL_NORMW
 #define MSMV_OWN_MFMA(WA, G0, G1) asm volatile("" ::"v"(WA), "v"(G0), "v"(G1));
@@ -830,69 +846,77 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
 #endif
 
                 if constexpr (STAGED) {
-                    // ---- all rows of the round: global -> LDS, 1 KiB per wave instruction
-                    constexpr int RPI = 64 / ROW_F4;                   // records per instruction
-                    constexpr int MAXI = QC / RPI;
-                    // records are applied in pairs: with an odd count the last pair's second record
-                    // is a null record (weights 0), and its row must be loaded too - 0 times
-                    // whatever an earlier kernel left in LDS can be NaN
-                    const int ninstr = (cnt + (cnt & 1) + RPI - 1) / RPI;
-                    int rpt[MAXI];
-                    const float *rgo[MAXI];
+                    // ---- the round's gradient rows: global -> LDS by direct loads, 1 KiB per wave
+                    // instruction, as a pipeline of UNITS (whole pairs of records and whole load
+                    // instructions): the staging area holds NS units, the loads of unit v + D are
+                    // issued before unit v is applied, and a counted wait leaves them in flight
+                    // (vector memory operations complete in order).  Every slot of the queue holds a
+                    // record with a valid point (null records have zero weights), so whole units are
+                    // loaded and applied without per-record tests - 0 times whatever an earlier
+                    // kernel left in LDS could be NaN, hence no row is ever left unloaded.
+                    constexpr int RPI = 64 / ROW_F4;                   // records per load instruction
+                    constexpr int UNIT_REC = RPI < 2 ? 2 : RPI;        // records per unit
+                    constexpr int IPU = UNIT_REC / RPI;                // load instructions per unit
+                    constexpr int PPU = UNIT_REC / 2;                  // pairs per unit
+                    constexpr int UNIT_F4 = UNIT_REC * ROW_F4;
+                    constexpr int NS = STAGE_F4 / UNIT_F4;             // units the staging area holds
+                    constexpr int D = NS - 1;                          // units in flight ahead of the one applied
+                    constexpr int NU = QC / UNIT_REC;                  // units per full round
+                    static_assert(NS >= 2 && NU * UNIT_REC == QC && D * IPU <= 3, "pipeline shape");
+                    const int nunits = (cnt + UNIT_REC - 1) / UNIT_REC;
+                    auto issue = [&](int v) {                          // (v is a constant after unrolling)
 #pragma unroll
-                    for (int i = 0; i < MAXI; ++i) {                   // the record this lane copies a piece of
-                        rpt[i] = __float_as_int(queue[(i * RPI + lane / ROW_F4) * REC_DW]);
-                        rgo[i] = gout;
-                        if constexpr (MULTI)
-                            rgo[i] = gout_tab[__float_as_int(queue[(i * RPI + lane / ROW_F4) * REC_DW + 1])];
-                    }
-#pragma unroll
-                    for (int i = 0; i < MAXI; ++i) {
-                        if (i < ninstr) {                              // wave-uniform
-                            const int row = PT == 4 ? rpt[i] >> 2 : PT == 2 ? rpt[i] >> 1 : rpt[i];
-                            const float *src = rgo[i] + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
-                            __builtin_amdgcn_global_load_lds((msmv_gptr_t)src, (msmv_lptr_t)(stage + i * 64), 16, 0, 0);
-                        }
-                    }
-                    // ---- apply: half-wave `half` takes record 2*pair + half.  Fully unrolled, so
-                    // that every LDS address is a lane constant plus an immediate.  The weights of
-                    // all pairs (null records included: their tables are zero) are fetched from the
-                    // queue while the rows are still on their way; the rows are then read one pair
-                    // ahead of the product that uses them.
-                    constexpr int NP = QC / 2;
-                    float wa[NP];
-                    [[maybe_unused]] int poff[NP];
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        wa[u] = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
-                        if constexpr (PT != 1)
-                            poff[u] = __float_as_int(q_pt[u * 2 * REC_DW]) & (PT - 1);
-                    }
-                    const float *sp0 = reinterpret_cast<const float *>(stage + half * ROW_F4) + l32 * (PT == 1 ? 1 : PT);
-                    auto row_read = [&](int u, float &g0, float &g1) {
-                        const float *sp = sp0 + u * 2 * ROW_F4 * 4;
-                        if constexpr (PT == 1) {
-                            g0 = sp[0];
-                            g1 = sp[32];
-                        } else {
-                            g0 = sp[poff[u]];
-                            g1 = sp[32 * PT + poff[u]];
+                        for (int j = 0; j < IPU; ++j) {
+                            const int rec = v * UNIT_REC + j * RPI + lane / ROW_F4;
+                            const int rpt = __float_as_int(queue[rec * REC_DW]);
+                            const float *go = gout;
+                            if constexpr (MULTI)
+                                go = gout_tab[__float_as_int(queue[rec * REC_DW + 1])];
+                            const int row = PT == 4 ? rpt >> 2 : PT == 2 ? rpt >> 1 : rpt;
+                            const float *src = go + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
+                            __builtin_amdgcn_global_load_lds((msmv_gptr_t)src,
+                                                             (msmv_lptr_t)(stage + (v % NS) * UNIT_F4 + j * 64), 16, 0, 0);
                         }
                     };
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    float g0, g1;
-                    row_read(0, g0, g1);
 #pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        if (u < npairs) {                              // wave-uniform
-                            float n0 = 0.f, n1 = 0.f;
-                            if (u + 1 < NP)
-                                row_read(u + 1, n0, n1);               // (stale but harmless when pair u + 1 does not exist)
-                            MSMV_OWN_MFMA(wa[u], g0, g1)
-                            if constexpr (ACC)
-                                touched = touched || wa[u] != 0.f;
-                            g0 = n0;
-                            g1 = n1;
+                    for (int v = 0; v < D; ++v)
+                        if (v < nunits)                                // wave-uniform
+                            issue(v);
+#pragma unroll
+                    for (int v = 0; v < NU; ++v) {
+                        if (v < nunits) {                              // wave-uniform
+                            if (v + D < NU && v + D < nunits)
+                                issue(v + D);
+                            // loads issued after unit v's: those of min(D, nunits - 1 - v) units
+                            const int ahead = min(D, nunits - 1 - v) * IPU;
+                            if (ahead >= 3)
+                                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                            else if (ahead == 2)
+                                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            else if (ahead == 1)
+                                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                            else
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            const float *sp0 = reinterpret_cast<const float *>(stage + (v % NS) * UNIT_F4 + half * ROW_F4) +
+                                               l32 * (PT == 1 ? 1 : PT);
+#pragma unroll
+                            for (int k2 = 0; k2 < PPU; ++k2) {
+                                const int u = v * PPU + k2;            // pair: records 2u and 2u + 1
+                                const float wa = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
+                                const float *sp = sp0 + k2 * 2 * ROW_F4 * 4;
+                                float g0, g1;
+                                if constexpr (PT == 1) {
+                                    g0 = sp[0];
+                                    g1 = sp[32];
+                                } else {
+                                    const int p = __float_as_int(q_pt[u * 2 * REC_DW]) & (PT - 1);
+                                    g0 = sp[p];
+                                    g1 = sp[32 * PT + p];
+                                }
+                                MSMV_OWN_MFMA(wa, g0, g1)
+                                if constexpr (ACC)
+                                    touched = touched || wa != 0.f;
+                            }
                         }
                     }
                     // the next round's copies and queue writes must not overtake this round's LDS reads
@@ -930,6 +954,7 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         }
     }
 
+    MSMV_DBG_STAMP(3)
     // ---- K > 1: sum the K partial tiles of a patch, halving the live waves per round.  The
     // round count is the workgroup's (one level, one K): every wave reaches every barrier.
     if (K > 1)
@@ -955,6 +980,18 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         }
         __syncthreads();
     }
+    MSMV_DBG_STAMP(4)
+#ifdef MSMV_DBG_TIMES
+    if (sub != 0 || idle) {
+        if (lane == 0 && msmv_dbg_buf) {
+            unsigned long long *o = msmv_dbg_buf + ((size_t)blockIdx.x * OWN_WAVES + wave) * 8;
+            o[0] = dbg_t[0]; o[1] = dbg_t[1]; o[2] = dbg_t[2]; o[3] = dbg_t[3]; o[4] = dbg_t[4]; o[5] = 0;
+            o[6] = ((unsigned long long)l << 32) | (unsigned)total;
+            o[7] = ((unsigned long long)b << 32) | ((unsigned)view << 16) | (unsigned)(idle ? 0xFFFF : sub);
+        }
+        return;
+    }
+#endif
     if (sub != 0 || idle)
         return;
     if constexpr (ACC) {
@@ -1032,6 +1069,16 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
             }
         }
     }
+#ifdef MSMV_DBG_TIMES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (what s_endpgm would wait for anyway: the stores' drain)
+    MSMV_DBG_STAMP(5)
+    if (lane == 0 && msmv_dbg_buf) {
+        unsigned long long *o = msmv_dbg_buf + ((size_t)blockIdx.x * OWN_WAVES + wave) * 8;
+        o[0] = dbg_t[0]; o[1] = dbg_t[1]; o[2] = dbg_t[2]; o[3] = dbg_t[3]; o[4] = dbg_t[4]; o[5] = dbg_t[5];
+        o[6] = ((unsigned long long)l << 32) | (unsigned)total;
+        o[7] = ((unsigned long long)b << 32) | ((unsigned)view << 16) | (unsigned)sub;
+    }
+#endif
 }
 
 // ======================================================================================
@@ -1364,6 +1411,13 @@ hipError_t msmv_launch_dfeat_sets(const MsmvArgs &a, int nsets, const float *con
 }
 
 int msmv_dfeat_max_sets() { return OWN_MAX_SETS; }
+
+#ifdef MSMV_DBG_TIMES
+extern "C" int opus_msmv_debug_set_buffer(void *p)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(msmv_dbg_buf), &p, sizeof(p));
+}
+#endif
 
 hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate)
 {

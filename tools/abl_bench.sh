@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: bench.py once per library build given on the command line (paths
 # relative to the repo), printing step time and per-kernel medians.  WL / PTS choose workload / points.
 for lib in "$@"; do
-  OPUS_MSMV_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload ${WL:-L-fwdbwd} --points ${PTS:-uniform} --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/abl_tmp.json 2>/dev/null || { echo "FAILED $lib"; continue; }
+  OPUS_MSMV_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload ${WL:-L-fwdbwd} --points ${PTS:-uniform} --steps ${STEPS:-100} --warmup 5 --no-cpu-baseline > gpurun_out/abl_tmp.json 2>/dev/null || { echo "FAILED $lib"; continue; }
   python - "$lib" <<'PY'
 import json,sys
 d=json.load(open("gpurun_out/abl_tmp.json"))
