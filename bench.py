@@ -78,6 +78,10 @@ def parse_args(argv=None):
                     help="decoder workloads: how the layers' d feats are summed - 'deferred': every layer sorts "
                          "and gathers, one d-feat pass over all layers at the end writes d feats once; "
                          "'accumulate': the first layer's backward writes them, the others add to them")
+    ap.add_argument("--fwd-order", default="bin", choices=["bin", "input"],
+                    help="caller-layout workloads (sampling4d-*): 'bin' sorts the points once per layer and runs "
+                         "the forward in bin order, the backward re-using the sort; 'input': forward in input "
+                         "order, the backward sorts for itself")
     ap.add_argument("--split-sample", action="store_true",
                     help="single-sample latency mode: the 32*batch slabs are split across the ranks (strong "
                          "scaling, still no data-path collective) instead of one whole batch per rank")
@@ -202,6 +206,8 @@ def alg_bytes(npts, feat_bytes):
     small = 12 + 4 * L                        # loc + weights (or their gradients)
     return {
         "msmv_fwd_c64": npts * (corner + vec + small),
+        "msmv_fwd_sorted": npts * (corner + vec + small),
+        "msmv_sort+fwd_sorted": npts * (corner + vec + small),
         "msmv_bwd_owner_dfeat": npts * (vec + small + corner) + feat_bytes,
         "msmv_bwd_owner_dfeat(accumulate)": npts * (vec + small + corner) + 2 * feat_bytes,
         "msmv_bwd_gather_c64": npts * (corner + small),
@@ -223,6 +229,8 @@ def compulsory_bytes(npts, feat_bytes, uniq, n_layers):
     per_set = npts * (vec + entry)            # a layer's gradient rows + sorted entries
     return {
         "msmv_fwd_c64": uniq + npts * (vec + small),
+        "msmv_fwd_sorted": uniq + npts * (vec + entry),
+        "msmv_sort+fwd_sorted": uniq + npts * (vec + entry) + npts * (small + entry),
         "msmv_bwd_owner_dfeat": feat_bytes + per_set,
         "msmv_bwd_owner_dfeat(accumulate)": 2 * uniq + per_set,       # touched pixels read and written back
         f"msmv_bwd_owner_dfeat({n_layers} layers)": feat_bytes + n_layers * per_set,
@@ -238,7 +246,7 @@ def compulsory_bytes(npts, feat_bytes, uniq, n_layers):
 class Step:
     """One decoder layer's forward (+ backward) with an event pair around every launch."""
 
-    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1, caller=None, defer=False):
+    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1, caller=None, defer=False, fwd_sorted=False):
         self.feats, self.sets, self.do_bwd, self.n_fwd = feats, sets, do_bwd, n_fwd
         self.algo = algo
         # deferred d feats: every layer sorts and gathers into a workspace of its own, one
@@ -248,6 +256,9 @@ class Step:
         # includes the projection kernels and the op runs in row mode ([B,Q,G,T*P,C] tensors)
         self.caller = caller
         self.rows = (8, 4) if caller else None
+        # bin-ordered forward (row mode only): the layer's sort is made by its first forward and
+        # serves its other forwards and its backward
+        self.fwd_sorted = bool(fwd_sorted and caller and algo == "owner")
         loc, w, _ = sets[0]
         if caller:
             self.dpts = torch.empty_like(caller[0][0])
@@ -289,11 +300,28 @@ class Step:
                     pts, sw, occ2img = self.caller[layer]
                     self._timed("msmv_project_pack", lambda: opus_sampling.project_pack_into(
                         pts, sw, occ2img, 256, 704, N_VIEWS, loc, w), record)
-                self._timed("msmv_fwd_c64", lambda: wrapper.msmv_forward(self.feats, loc, w, rows=rows), record)
+                if self.fwd_sorted:
+                    ws_l = self.ws_per_layer[layer] if self.ws_per_layer else self.ws
+                    self._timed("msmv_sort+fwd_sorted" if _ == 0 else "msmv_fwd_sorted",
+                                lambda pre=_ > 0: wrapper.msmv_forward_sorted(self.feats, loc, w, rows=rows, workspace=ws_l,
+                                                                              presorted=pre), record)
+                else:
+                    self._timed("msmv_fwd_c64", lambda: wrapper.msmv_forward(self.feats, loc, w, rows=rows), record)
             if not self.do_bwd:
                 continue
             args = (g, self.feats, loc, w, self.dfeats, self.dloc, self.dw, self.ws)
-            if self.defer:
+            if self.fwd_sorted and self.defer:
+                self._timed("msmv_bwd_gather_c64", lambda: wrapper.msmv_backward_into(
+                    g, self.feats, loc, w, None, self.dloc, self.dw, self.ws_per_layer[layer],
+                    flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED | _lib.BWD_STAGE_GATHER, rows=rows), record)
+            elif self.fwd_sorted and not record:
+                wrapper.msmv_backward_into(*args, flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED | acc, rows=rows)
+            elif self.fwd_sorted:
+                for name, bit in (("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT), ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
+                    self._timed(name if not (acc and bit == _lib.BWD_STAGE_DFEAT) else name + "(accumulate)",
+                                lambda bit=bit: wrapper.msmv_backward_into(
+                                    *args, flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED | bit | acc, rows=rows), record)
+            elif self.defer:
                 dargs = (g, self.feats, loc, w, None, self.dloc, self.dw, self.ws_per_layer[layer])
                 if not record:
                     wrapper.msmv_backward_into(*dargs, flags=_lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER,
@@ -468,7 +496,8 @@ def main():
             if wl.startswith("sampling4d-"):
                 caller = cam
                 sets = [(loc, w, g.reshape(args.batch, Q, 4, 8 * P, CHANNELS)) for loc, w, g in sets]
-        step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd, caller=caller, defer=args.dfeat == "deferred")
+        step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd, caller=caller, defer=args.dfeat == "deferred",
+                    fwd_sorted=args.fwd_order == "bin")
     npts_step = Bp * Q * P * n_layers                    # sampled points per step per rank
     feat_bytes = sum(f.numel() * 4 for f in feats)
 
@@ -615,6 +644,7 @@ def main():
                        "levels": LEVELS, "channels": CHANNELS, "batch_per_gpu": args.batch,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
                        "dfeat_sum": ("deferred" if step.defer else "accumulate") if n_layers > 1 and do_bwd else None,
+                       "fwd_order": "bin" if getattr(step, "fwd_sorted", False) else "input",
                        "points": args.points if (not caller or args.points != "uniform") else "cameras",
                        "launch": ("HIP graph replay" if args.graph else
                                   f"one call per kernel; HIP events between them in every {args.event_every}. timed step")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OPUS_MSMV_VERSION 100          /* major*10000 + minor*100 + patch */
+#define OPUS_MSMV_VERSION 200          /* major*10000 + minor*100 + patch */
 #define OPUS_MSMV_MAX_LEVELS 8
 #define OPUS_MSMV_MAX_POINTS 32        /* MAX_POINT, msmv_sampling_forward.cu:21, msmv_sampling.cpp:125 */
 
@@ -65,11 +65,17 @@ enum {
  * so that a profiler or benchmark can time each kernel with events of its own.  The stages
  * must be issued in this order on one stream with the same arguments and workspace; no
  * stage bit set means all three.  `dfeats` may be NULL when STAGE_DFEAT is not among the
- * stages asked for (see opus_msmv_dfeat_multi).  No counterpart in the reference. */
+ * stages asked for (see opus_msmv_dfeat_multi); `dloc` / `dweights` when STAGE_GATHER is not
+ * (the sort reads `loc` and `weights` only).  No counterpart in the reference. */
 #define OPUS_MSMV_BWD_STAGE_BIN 0x100      /* sort the points into (batch, view, band) bins */
 #define OPUS_MSMV_BWD_STAGE_DFEAT 0x200    /* d feats, one owner per run of pixels */
 #define OPUS_MSMV_BWD_STAGE_GATHER 0x400   /* d loc and d weights */
 #define OPUS_MSMV_BWD_STAGE_MASK 0x700
+/* OR-ed into `flags` (owner algorithm only): `workspace` already holds the sort of these very
+ * `loc` / `weights`, left there by opus_msmv_forward_sorted() or by a backward's sort stage with
+ * the same sizes (and, in row mode, the same T and G): the sort stage is skipped.  Not to be combined with
+ * OPUS_MSMV_BWD_STAGE_BIN.  No counterpart in the reference. */
+#define OPUS_MSMV_BWD_PRESORTED 0x800
 
 /* Library version (OPUS_MSMV_VERSION it was built with). */
 int opus_msmv_version(void);
@@ -168,6 +174,28 @@ int opus_msmv_backward_rows(int L, const float *grad_out, const float *const *fe
                             int Bs, int T, int G, int C, int N, int Q, int P,
                             float *const *dfeats, float *dloc, float *dweights,
                             void *workspace, size_t workspace_bytes, int flags, void *stream);
+
+/*
+ * Forward in bin order.  No counterpart in the reference.  The points of every batch slab are
+ * first sorted by (view, image band) - the backward's sort, written into `workspace`
+ * (>= opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, OPUS_MSMV_BWD_OWNER) bytes) - and the
+ * forward then walks them in that order, so that neighbouring points fetch neighbouring pixels
+ * and the feature traffic approaches the distinct pixels touched.  Results are bit-identical to
+ * opus_msmv_forward_rows / opus_msmv_forward.  In a training step the sort serves three passes:
+ * the forward, the forward re-run under activation checkpointing (OPUS_MSMV_FWD_PRESORTED) and
+ * the backward (OPUS_MSMV_BWD_PRESORTED), as long as `loc`, `weights` and the workspace are kept.
+ *   T >= 1: row mode, B = Bs*T*G, out [Bs, Q, G, T*P, C] (see opus_msmv_forward_rows).
+ *   T == 0: out [B = Bs, Q, C, P]; P must be 1 (for larger P a point's channels are P-strided in
+ *           that layout and bin order would scatter 4-byte pieces).
+ * flags: 0 or OPUS_MSMV_FWD_PRESORTED (the workspace already holds the sort of these loc /
+ * weights).  OPUS_MSMV_EINVAL_FLAGS where the sort does not apply (C != 64, L outside {4,5},
+ * N > 16, pointers not 16-byte aligned, T == 0 with P > 1): call opus_msmv_forward_rows then.
+ */
+#define OPUS_MSMV_FWD_PRESORTED 0x4
+int opus_msmv_forward_sorted(int L, const float *const *feats, const int *hw,
+                             const float *loc, const float *weights,
+                             int Bs, int T, int G, int C, int N, int Q, int P,
+                             float *out, void *workspace, size_t workspace_bytes, int flags, void *stream);
 
 /*
  * Deferred d feats for a stack of layers that sample the same feature maps (the decoder calls

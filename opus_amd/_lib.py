@@ -17,6 +17,8 @@ BWD_ACCUMULATE = 0x10
 FWD_GENERIC = 0x1
 PACK_SHARED_FRAMES = 0x1
 BWD_STAGE_BIN, BWD_STAGE_DFEAT, BWD_STAGE_GATHER = 0x100, 0x200, 0x400
+BWD_PRESORTED = 0x800
+FWD_PRESORTED = 0x4
 MAX_LEVELS = 8
 MAX_POINTS = 32
 NOALLOC_SCRATCH_BYTES = 32 << 20
@@ -58,6 +60,9 @@ SYMBOLS = {
         ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 7
         + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,
            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
+    "opus_msmv_forward_sorted": (ctypes.c_int, [
+        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _i32p, ctypes.c_void_p, ctypes.c_void_p]
+        + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_dfeat_max_sets": (ctypes.c_int, []),
     "opus_msmv_dfeat_multi": (ctypes.c_int, [
         ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),

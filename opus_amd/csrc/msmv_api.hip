@@ -179,6 +179,46 @@ int opus_msmv_forward_rows(int L, const float *const *feats, const int *hw,
     return forward_impl(L, feats, hw, loc, weights, Bs * T * G, T, G, C, N, Q, P, out, flags, stream);
 }
 
+int opus_msmv_forward_sorted(int L, const float *const *feats, const int *hw,
+                             const float *loc, const float *weights,
+                             int Bs, int T, int G, int C, int N, int Q, int P,
+                             float *out, void *workspace, size_t workspace_bytes, int flags, void *stream)
+{
+    if (Bs < 0 || T < 0 || (T > 0 && G < 1) || (T > 0 && (long long)Bs * T * G > INT_MAX))
+        return OPUS_MSMV_EINVAL_DIMS;
+    const int B = T ? Bs * T * G : Bs;
+    MsmvArgs a = {};
+    int rc = fill_common(a, L, hw, B, C, N, Q, P);
+    if (rc == OPUS_MSMV_OK && T)
+        rc = fill_rows(a, T, G);
+    if (rc != OPUS_MSMV_OK)
+        return rc;
+    if (flags & ~OPUS_MSMV_FWD_PRESORTED)
+        return OPUS_MSMV_EINVAL_FLAGS;
+    if (!msmv_backward_owner_supported(a) || (!T && P != 1))
+        return OPUS_MSMV_EINVAL_FLAGS;
+    if (B == 0)
+        return OPUS_MSMV_OK;
+    if (!feats || (a.npts > 0 && (!loc || !weights || !out)))
+        return OPUS_MSMV_EINVAL_PTR;
+    if (!aligned16(out) || !aligned16(weights))
+        return OPUS_MSMV_EINVAL_FLAGS;
+    for (int l = 0; l < L; ++l) {
+        if (!feats[l])
+            return OPUS_MSMV_EINVAL_PTR;
+        if (!aligned16(feats[l]))
+            return OPUS_MSMV_EINVAL_FLAGS;
+        a.lvl[l].feat = feats[l];
+    }
+    if (!workspace || workspace_bytes < msmv_backward_owner_workspace(B, N, Q, P) || !aligned16(workspace))
+        return OPUS_MSMV_EWORKSPACE;
+    a.loc = loc;
+    a.w = weights;
+    a.out = out;
+    return msmv_launch_forward_sorted(a, workspace, (hipStream_t)stream, (flags & OPUS_MSMV_FWD_PRESORTED) != 0) == hipSuccess
+               ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
+}
+
 size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int P, int flags)
 {
     const int algo = flags & 0xF;
@@ -207,11 +247,19 @@ static int backward_impl(int L, const float *grad_out, const float *const *feats
         return rc;
     const int algo = flags & 0xF;
     const bool accumulate = (flags & OPUS_MSMV_BWD_ACCUMULATE) != 0;
-    const int stage_bits = flags & OPUS_MSMV_BWD_STAGE_MASK;
-    if ((flags & ~(0xF | OPUS_MSMV_BWD_ACCUMULATE | OPUS_MSMV_BWD_STAGE_MASK)) || algo > OPUS_MSMV_BWD_OWNER)
+    int stage_bits = flags & OPUS_MSMV_BWD_STAGE_MASK;
+    const bool presorted = (flags & OPUS_MSMV_BWD_PRESORTED) != 0;
+    if ((flags & ~(0xF | OPUS_MSMV_BWD_ACCUMULATE | OPUS_MSMV_BWD_STAGE_MASK | OPUS_MSMV_BWD_PRESORTED)) ||
+        algo > OPUS_MSMV_BWD_OWNER)
         return OPUS_MSMV_EINVAL_FLAGS;
-    if (stage_bits && algo != OPUS_MSMV_BWD_OWNER)
+    if ((stage_bits || presorted) && algo != OPUS_MSMV_BWD_OWNER)
         return OPUS_MSMV_EINVAL_FLAGS;
+    if (presorted) {
+        if (stage_bits & OPUS_MSMV_BWD_STAGE_BIN)
+            return OPUS_MSMV_EINVAL_FLAGS;
+        if (!stage_bits)
+            stage_bits = OPUS_MSMV_BWD_STAGE_DFEAT | OPUS_MSMV_BWD_STAGE_GATHER;
+    }
     // d feats may be absent when the stages asked for leave them alone (sort and / or gather only)
     const bool need_dfeat = algo != OPUS_MSMV_BWD_OWNER || !stage_bits || (stage_bits & OPUS_MSMV_BWD_STAGE_DFEAT);
     if (!feats || (need_dfeat && !dfeats))
@@ -222,10 +270,8 @@ static int backward_impl(int L, const float *grad_out, const float *const *feats
         a.lvl[l].feat = feats[l];
         a.lvl[l].dfeat = dfeats ? dfeats[l] : nullptr;
     }
-    // d loc / d weights are written by the gather stage and, for points without a valid view, by
-    // the sort stage; the d-feat stage alone leaves them alone
-    const bool need_dlw = algo != OPUS_MSMV_BWD_OWNER || !stage_bits ||
-                          (stage_bits & (OPUS_MSMV_BWD_STAGE_BIN | OPUS_MSMV_BWD_STAGE_GATHER));
+    // d loc / d weights are written by the gather stage only
+    const bool need_dlw = algo != OPUS_MSMV_BWD_OWNER || !stage_bits || (stage_bits & OPUS_MSMV_BWD_STAGE_GATHER);
     if (a.npts > 0 && (!grad_out || !loc || !weights || (need_dlw && (!dloc || !dweights))))
         return OPUS_MSMV_EINVAL_PTR;
     a.loc = loc;

@@ -130,14 +130,19 @@ constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_KEYS = 4096;       // N * BIN_PER_VIEW must not exceed this (N <= 16)
 
 // workspace layout:
-//   [ counts: B*keys ints ][ cursors: B*keys ints ]   cleared by a memset node every call
+//   [ counts: B*keys ints ][ cursors: B*keys ints ][ tails: B ints ]   cleared by a memset node every call
 //   [ offsets: B*(keys+1) ints ]  (padded to 256 B)   exclusive prefix of the counts per batch
 //   [ entries: npts * 32 B ]
 // entries of batch b occupy [b*QP, b*QP + offsets[b][keys]), sorted by
-// key = (view*BIN_YB + yband)*BIN_XB + xband (order inside a key is arbitrary).
+// key = (view*BIN_YB + yband)*BIN_XB + xband (order inside a key is arbitrary).  The slab's other
+// slots, [b*QP + offsets[b][keys], (b+1)*QP), hold its points without a valid view (in no bin, view
+// -1 in the entry): the d-feat pass, which walks bins, never meets them; the passes that walk all
+// QP slots of a slab (gather, bin-ordered forward) write their all-zero results.  The sort thus
+// reads loc and weights only, and one sort serves forward and backward passes alike.
 struct OwnerWs {
     int *counts;
     int *cursors;
+    int *tails;           // per slab: points without a valid view placed so far (filled from the slab's last slot down)
     int *offsets;
     BinEntry *entries;
     int keys;             // N * BIN_PER_VIEW
@@ -146,7 +151,7 @@ struct OwnerWs {
 
 __host__ __device__ inline size_t owner_ws_clear_bytes(int B, int N)
 {
-    return (size_t)B * N * BIN_PER_VIEW * 2 * sizeof(int);
+    return ((size_t)B * N * BIN_PER_VIEW * 2 + (size_t)B) * sizeof(int);
 }
 
 __host__ __device__ inline size_t owner_ws_header_bytes(int B, int N)
@@ -190,6 +195,23 @@ __device__ __forceinline__ void msmv_band_range(int lo, int hi, int size, MsmvDi
         const int qh = (int)msmv_div((uint32_t)(NB * (hi + 1)), sm1) + wide;
         b_hi = min(qh, NB - 1);
     }
+}
+
+// The entry of point pt (location x, y, bin key or -1) at slot `pos` of its slab.
+__device__ __forceinline__ void msmv_put_entry(const MsmvArgs &a, const OwnerWs &ws, int b, int pos, size_t pt,
+                                               float x, float y, int key)
+{
+    const float *wp = a.w + pt * a.L;
+    float wv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        wv[k] = k < a.L ? wp[k] : 0.f;
+    if (a.L <= 4)
+        wv[4] = __int_as_float(key < 0 ? -1 : key / BIN_PER_VIEW);     // the view, for the passes that walk the slots
+    float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + pos);
+    const int id = a.rows ? msmv_row_of((int)pt, a) : (int)pt;
+    e[0] = make_float4(__int_as_float(id), x, y, wv[0]);
+    e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
 }
 
 __device__ __forceinline__ int msmv_bin_key(const float *lp, int N)
@@ -268,6 +290,7 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
     __shared__ int hist[BIN_MAX_KEYS];        // local counts, then the claimed base per key
     __shared__ int incl[BIN_MAX_KEYS];        // the slab's counts, then their inclusive prefix
     __shared__ int wave_tot[BIN_THREADS / 64];
+    __shared__ int tail_n;                    // this workgroup's points without a valid view, then their base
     const int tid = threadIdx.x;
     const int b = blockIdx.x / ws.chunks, chunk = blockIdx.x % ws.chunks;
     const int i = chunk * BIN_THREADS + tid;
@@ -278,6 +301,8 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
         hist[k] = 0;
         incl[k] = ws.counts[(size_t)b * keys + k];
     }
+    if (tid == 0)
+        tail_n = 0;
     __syncthreads();
     int key = -1, rank = 0;
     float x = 0.f, y = 0.f;
@@ -286,10 +311,11 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
         x = lp[0];
         y = lp[1];
         key = msmv_bin_key(lp, a.N);
-        if (key >= 0)
-            rank = atomicAdd(&hist[key], 1);
+        rank = atomicAdd(key >= 0 ? &hist[key] : &tail_n, 1);
     }
     msmv_block_scan(incl, keys, wave_tot);    // (its first barrier also orders the LDS atomics above)
+    if (tid == 0 && tail_n)
+        tail_n = atomicAdd(ws.tails + b, tail_n);
     for (int k = tid; k < keys; k += BIN_THREADS) {
         const int n = hist[k];
         const int excl = incl[k] - ws.counts[(size_t)b * keys + k];
@@ -302,27 +328,8 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
         }
     }
     __syncthreads();
-    if (i < a.qp && key < 0) {
-        // a point without a valid view is in no bin: its gradients are zero, written here
-        // because the bin-ordered gather pass never sees it
-        float *dl = a.dloc + pt * 3;
-        dl[0] = 0.f; dl[1] = 0.f; dl[2] = 0.f;
-        for (int k = 0; k < a.L; ++k)
-            a.dw[pt * a.L + k] = 0.f;
-    }
-    if (key >= 0) {
-        const float *wp = a.w + pt * a.L;
-        float wv[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            wv[k] = k < a.L ? wp[k] : 0.f;
-        if (a.L <= 4)
-            wv[4] = __int_as_float(key / BIN_PER_VIEW);     // the view, for the gather pass
-        float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + hist[key] + rank);
-        const int id = a.rows ? msmv_row_of((int)pt, a) : (int)pt;
-        e[0] = make_float4(__int_as_float(id), x, y, wv[0]);
-        e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
-    }
+    if (i < a.qp)
+        msmv_put_entry(a, ws, b, key >= 0 ? hist[key] + rank : a.qp - 1 - (tail_n + rank), pt, x, y, key);
 }
 
 // Small slabs (at most BIN_ONE_PPT * BIN_THREADS points, e.g. OPUS-T / S): the whole counting
@@ -339,11 +346,14 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
     __shared__ int hist[BIN_MAX_KEYS];
     __shared__ int incl[BIN_MAX_KEYS];
     __shared__ int wave_tot[BIN_THREADS / 64];
+    __shared__ int tail_n;                    // points without a valid view
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int keys = ws.keys;
     for (int k = tid; k < keys; k += BIN_THREADS)
         hist[k] = 0;
+    if (tid == 0)
+        tail_n = 0;
     __syncthreads();
     int key[BIN_ONE_PPT], rank[BIN_ONE_PPT];
     float x[BIN_ONE_PPT], y[BIN_ONE_PPT];
@@ -358,8 +368,7 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
             x[u] = lp[0];
             y[u] = lp[1];
             key[u] = msmv_bin_key(lp, a.N);
-            if (key[u] >= 0)
-                rank[u] = atomicAdd(&hist[key[u]], 1);
+            rank[u] = atomicAdd(key[u] >= 0 ? &hist[key[u]] : &tail_n, 1);
         }
     }
     __syncthreads();
@@ -378,26 +387,9 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
     for (int u = 0; u < BIN_ONE_PPT; ++u) {
         const int i = u * BIN_THREADS + tid;
         const size_t pt = (size_t)b * a.qp + i;
-        if (i < a.qp && key[u] < 0) {
-            // no valid view: in no bin, zero gradients (the bin-ordered gather never sees it)
-            float *dl = a.dloc + pt * 3;
-            dl[0] = 0.f; dl[1] = 0.f; dl[2] = 0.f;
-            for (int k = 0; k < a.L; ++k)
-                a.dw[pt * a.L + k] = 0.f;
-        }
-        if (key[u] >= 0) {
-            const float *wp = a.w + pt * a.L;
-            float wv[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-                wv[k] = k < a.L ? wp[k] : 0.f;
-            if (a.L <= 4)
-                wv[4] = __int_as_float(key[u] / BIN_PER_VIEW);     // the view, for the gather pass
-            const int pos = incl[key[u]] - hist[key[u]] + rank[u];
-            float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + pos);
-            const int id = a.rows ? msmv_row_of((int)pt, a) : (int)pt;
-            e[0] = make_float4(__int_as_float(id), x[u], y[u], wv[0]);
-            e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
+        if (i < a.qp) {
+            const int pos = key[u] >= 0 ? incl[key[u]] - hist[key[u]] + rank[u] : a.qp - 1 - rank[u];
+            msmv_put_entry(a, ws, b, pos, pt, x[u], y[u], key[u]);
         }
     }
 }
@@ -1121,15 +1113,11 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
         [[maybe_unused]] int grow = 0;           // row mode: the point's grad_out row
         static_assert(PT != MSMV_PT_ROWS || SORTED, "row mode walks the bin entries");
         if constexpr (SORTED) {
-            // slot pt of the entry array: slab b holds offsets[b][keys] entries from b*QP on
+            // slot pt of the entry array: every slot of slab b = [b*QP, (b+1)*QP) holds a point of it
             b = msmv_batch_of(pt, a);
-            const int n_b = ws.offsets[(size_t)b * (ws.keys + 1) + ws.keys];
-            act = act && (pt - b * a.qp) < n_b;
-            const float4 *e = reinterpret_cast<const float4 *>(ws.entries + (act ? pt : b * a.qp));
+            const float4 *e = reinterpret_cast<const float4 *>(ws.entries + pt);
             const float4 e0 = e[0], e1 = e[1];
-            if (n_b == 0)
-                act = false;                 // (the entry read above is then stale but in bounds)
-            pt = act ? __float_as_int(e0.x) : a.npts - 1;
+            pt = __float_as_int(e0.x);
             if constexpr (PT == MSMV_PT_ROWS) {
                 grow = pt;
                 pt = msmv_pt_of_row(grow, a);
@@ -1144,8 +1132,6 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
                 view = __float_as_int(e1.w);
             else
                 view = msmv_view_of(a.loc[(size_t)pt * 3 + 2], a.N);
-            if (!act)
-                view = -1;
         } else {
             const float *lp = a.loc + (size_t)pt * 3;
             lx = lp[0];
@@ -1246,11 +1232,12 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
         gx = msmv_row16_sum(gx);
         gy = msmv_row16_sum(gy);
         if (act && l16 == 0) {
+            // (a point without a valid view: exact zeros, whatever its gradient row holds)
             float *dl = a.dloc + (size_t)pt * 3;
-            dl[0] = gx; dl[1] = gy; dl[2] = 0.f;
+            dl[0] = view_ok ? gx : 0.f; dl[1] = view_ok ? gy : 0.f; dl[2] = 0.f;
 #pragma unroll
             for (int l = 0; l < NL; ++l)
-                a.dw[(size_t)pt * NL + l] = dwl[l];
+                a.dw[(size_t)pt * NL + l] = view_ok ? dwl[l] : 0.f;
         }
     }
 }
@@ -1270,6 +1257,82 @@ void launch_gather(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
     case 4: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 4, false>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     default: hipLaunchKernelGGL((msmv_bwd_gather_c64<NL, 0, false>), dim3(nblk), dim3(GAT_THREADS), 0, s, a, ws); break;
     }
+}
+
+// ======================================================================================
+// forward in bin order (row mode, or P == 1): the same row-of-16-lanes kernel as msmv_fwd_c64
+// (msmv_forward.hip), but walking the sorted entries, so that the rows a CU works on at one time
+// touch neighbouring pixels and the feature traffic approaches the distinct pixels touched.  In
+// training the sort is then the backward's too (OPUS_MSMV_BWD_PRESORTED).  A point's 64 channels
+// are one contiguous 256-byte row of the output; a point without a valid view (the tail slots of
+// its slab) gets a row of zeros like in input order.
+// ======================================================================================
+template <int NL>
+__global__ void __launch_bounds__(GAT_THREADS)
+msmv_fwd_sorted_c64(const MsmvArgs a, const OwnerWs ws)
+{
+    const int lane = threadIdx.x & 63;
+    const int sub = lane >> 4;
+    const int l16 = lane & 15;
+    const int wave = threadIdx.x >> 6;
+    const int blk = msmv_xcd_remap(blockIdx.x, gridDim.x);
+    const int ngroups = (a.npts + 3) >> 2;
+    const int g = blk * (GAT_THREADS / 64) + wave;
+    if (g >= ngroups)
+        return;
+    const int slot_raw = g * 4 + sub;
+    const bool act = slot_raw < a.npts;
+    const int slot = act ? slot_raw : a.npts - 1;
+    // slot of the entry array: every slot of slab b = [b*QP, (b+1)*QP) holds a point of it
+    const int b = msmv_batch_of(slot, a);
+    const float4 *e = reinterpret_cast<const float4 *>(ws.entries + slot);
+    const float4 e0 = e[0], e1 = e[1];
+    const int row = __float_as_int(e0.x);                    // output row (row mode) or point (P == 1)
+    const float lx = e0.y, ly = e0.z;
+    const float wv[5] = {e0.w, e1.x, e1.y, e1.z, e1.w};
+    float wl[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+        wl[l] = wv[l];
+    int view;
+    if constexpr (NL <= 4) {
+        view = __float_as_int(e1.w);
+    } else {
+        const int pt = a.rows ? msmv_pt_of_row(row, a) : row;
+        view = msmv_view_of(a.loc[(size_t)pt * 3 + 2], a.N);
+    }
+    const bool view_ok = view >= 0;
+    const size_t slab = (size_t)b * a.N + (view_ok ? view : 0);
+
+    MsmvTap tap[NL];
+    float4 v[NL][4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int H = a.lvl[l].H, W = a.lvl[l].W;
+        tap[l] = msmv_make_tap(lx, ly, H, W, view_ok);
+        const float *base = a.lvl[l].feat + (slab * (size_t)(H * W)) * 64 + l16 * 4;
+        v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l < MSMV_STREAM_LEVELS);
+        v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l < MSMV_STREAM_LEVELS);
+        v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l < MSMV_STREAM_LEVELS);
+        v[l][3] = ld4_level(base + (size_t)tap[l].o4 * 64, l < MSMV_STREAM_LEVELS);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const MsmvTap &t = tap[l];
+        // the arithmetic of msmv_fwd_c64, operation for operation: results are bit-identical
+#define MSMV_FWDS_CH(X)                                                            \
+        {                                                                          \
+            const float v1 = t.c1 ? v[l][0].X : 0.f, v2 = t.c2 ? v[l][1].X : 0.f;  \
+            const float v3 = t.c3 ? v[l][2].X : 0.f, v4 = t.c4 ? v[l][3].X : 0.f;  \
+            const float val = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;       \
+            acc.X = t.ok ? acc.X + val * wl[l] : acc.X;                            \
+        }
+        MSMV_FWDS_CH(x) MSMV_FWDS_CH(y) MSMV_FWDS_CH(z) MSMV_FWDS_CH(w)
+#undef MSMV_FWDS_CH
+    }
+    if (act)
+        *reinterpret_cast<float4 *>(a.out + (size_t)row * 64 + l16 * 4) = acc;
 }
 
 }  // namespace
@@ -1329,7 +1392,8 @@ static OwnerWs owner_ws_of(const MsmvArgs &a, void *workspace)
     ws.chunks = (a.qp + BIN_THREADS - 1) / BIN_THREADS;
     ws.counts = reinterpret_cast<int *>(workspace);
     ws.cursors = ws.counts + (size_t)a.B * ws.keys;
-    ws.offsets = ws.cursors + (size_t)a.B * ws.keys;
+    ws.tails = ws.cursors + (size_t)a.B * ws.keys;
+    ws.offsets = ws.tails + a.B;
     ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N));
     return ws;
 }
@@ -1419,28 +1483,53 @@ extern "C" int opus_msmv_debug_set_buffer(void *p)
 }
 #endif
 
+// The counting sort of every batch slab's points into `workspace` (see OwnerWs).
+static hipError_t launch_sort(const MsmvArgs &a, const OwnerWs &ws, void *workspace, hipStream_t s)
+{
+    hipError_t e;
+    if (a.qp > 0 && a.qp <= BIN_ONE_PPT * BIN_THREADS) {
+        hipLaunchKernelGGL(msmv_bin_one, dim3((unsigned)a.B), dim3(BIN_THREADS), 0, s, a, ws);
+        return hipSuccess;
+    }
+    if ((e = hipMemsetAsync(workspace, 0, owner_ws_clear_bytes(a.B, a.N), s)) != hipSuccess)
+        return e;
+    if (ws.chunks > 0) {
+        const dim3 grid((unsigned)(a.B * ws.chunks)), block(BIN_THREADS);
+        hipLaunchKernelGGL(msmv_bin_count, grid, block, 0, s, a, ws);
+        hipLaunchKernelGGL(msmv_bin_fill, grid, block, 0, s, a, ws);
+        return hipSuccess;
+    }
+    // no queries: the offsets must still read as "every bin empty"
+    return hipMemsetAsync(ws.offsets, 0, (size_t)a.B * (ws.keys + 1) * sizeof(int), s);
+}
+
+hipError_t msmv_launch_forward_sorted(const MsmvArgs &a, void *workspace, hipStream_t s, bool presorted)
+{
+    const OwnerWs ws = owner_ws_of(a, workspace);
+    const hipError_t stale = hipPeekAtLastError();
+    hipError_t e;
+    if (!presorted && (e = launch_sort(a, ws, workspace, s)) != hipSuccess)
+        return e;
+    if (a.npts > 0) {
+        const int ngroups = (a.npts + 3) / 4;
+        const int per_block = GAT_THREADS / 64;
+        const dim3 grid((unsigned)((ngroups + per_block - 1) / per_block)), block(GAT_THREADS);
+        if (a.L == 4)
+            hipLaunchKernelGGL((msmv_fwd_sorted_c64<4>), grid, block, 0, s, a, ws);
+        else
+            hipLaunchKernelGGL((msmv_fwd_sorted_c64<5>), grid, block, 0, s, a, ws);
+    }
+    return msmv_launch_status(stale);
+}
+
 hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate)
 {
     const OwnerWs ws = owner_ws_of(a, workspace);
     const hipError_t stale = hipPeekAtLastError();
 
     hipError_t e;
-    if ((stages & 1) && a.qp > 0 && a.qp <= BIN_ONE_PPT * BIN_THREADS) {
-        hipLaunchKernelGGL(msmv_bin_one, dim3((unsigned)a.B), dim3(BIN_THREADS), 0, s, a, ws);
-    } else if (stages & 1) {
-        if ((e = hipMemsetAsync(workspace, 0, owner_ws_clear_bytes(a.B, a.N), s)) != hipSuccess)
-            return e;
-        if (ws.chunks > 0) {
-            const dim3 grid((unsigned)(a.B * ws.chunks)), block(BIN_THREADS);
-            hipLaunchKernelGGL(msmv_bin_count, grid, block, 0, s, a, ws);
-            hipLaunchKernelGGL(msmv_bin_fill, grid, block, 0, s, a, ws);
-        } else {
-            // no queries: the offsets must still read as "every bin empty"
-            e = hipMemsetAsync(ws.offsets, 0, (size_t)a.B * (ws.keys + 1) * sizeof(int), s);
-            if (e != hipSuccess)
-                return e;
-        }
-    }
+    if ((stages & 1) && (e = launch_sort(a, ws, workspace, s)) != hipSuccess)
+        return e;
     if ((e = msmv_launch_status(stale)) != hipSuccess)
         return e;
 

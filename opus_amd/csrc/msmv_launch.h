@@ -29,6 +29,10 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P);
 // stages: bit 0 = bin, bit 1 = d feat tiles, bit 2 = d loc / d w gather
 hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStream_t s, int stages, bool accumulate);
 
+// Forward in bin order (owner-supported shapes; row mode, or P == 1): sorts into `workspace` unless
+// `presorted`.
+hipError_t msmv_launch_forward_sorted(const MsmvArgs &a, void *workspace, hipStream_t s, bool presorted);
+
 // Caller-side fusion (msmv_project.hip): projection + view selection + packing, and its backward.
 hipError_t msmv_launch_project_pack(const float *pts, const float *sw, const float *occ2img,
                                     int B, int Q, int T, int G, int P, int L, int N,

@@ -66,6 +66,19 @@ if _bwd_algo not in _BWD_ALGOS:
     raise ValueError(f"OPUS_MSMV_BWD_ALGO must be one of {sorted(_BWD_ALGOS)}, got {_bwd_algo!r}")
 
 
+# Bin-ordered forward (opus_msmv_forward_sorted) in the autograd Functions that can use it (row
+# mode and P == 1, owner backward): the sort made for the forward is kept and serves the backward.
+_fwd_sorted = os.environ.get("OPUS_MSMV_FWD_SORTED", "1") not in ("", "0")
+
+
+def set_forward_sorted(flag=True):
+    """Whether msmv_sampling_rows (and msmv_sampling with one point per query) run their forward
+    in bin order and hand the sort on to their backward.  Default on; OPUS_MSMV_FWD_SORTED=0 at
+    import turns it off."""
+    global _fwd_sorted
+    _fwd_sorted = bool(flag)
+
+
 def set_backward_algo(name):
     """'auto' (default), 'atomic' or 'owner' - see include/opus_msmv.h."""
     global _bwd_algo
@@ -168,6 +181,38 @@ def msmv_forward(feats, loc, w, flags=0, rows=None):
     return out
 
 
+def msmv_forward_sorted(feats, loc, w, rows=None, workspace=None, presorted=False):
+    """Forward in bin order -> (out, workspace) or None where it does not apply (then use
+    msmv_forward).  The workspace holds the sort: hand it to a later call with ``presorted=True``
+    (the same loc / weights) or to msmv_backward_into with ``_lib.BWD_PRESORTED``."""
+    L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
+    lib = _lib.load()
+    if rows is None and P != 1:
+        return None
+    need = lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, _lib.BWD_OWNER)
+    if need == 0:
+        return None
+    with torch.cuda.device(loc.device):
+        if workspace is None:
+            if presorted:
+                raise RuntimeError("presorted=True needs the workspace that holds the sort")
+            workspace = torch.empty(need, dtype=torch.uint8, device=loc.device)
+        if rows is None:
+            dims, shape = (B, 0, 0), (B, Q, C, P)
+        else:
+            Bs, T, G = _check_rows(B, rows)
+            dims, shape = (Bs, T, G), (Bs, Q, G, T * P, C)
+        out = torch.empty(shape, dtype=torch.float32, device=loc.device)
+        rc = lib.opus_msmv_forward_sorted(
+            L, _lib.ptr_array([f.data_ptr() for f in feats]), _lib.int_array(hw), loc.data_ptr(), w.data_ptr(),
+            *dims, C, N, Q, P, out.data_ptr(), workspace.data_ptr(), workspace.numel(),
+            _lib.FWD_PRESORTED if presorted else 0, _stream_ptr(loc.device))
+    if rc == -7:                                # EINVAL_FLAGS: shape / alignment the sort does not take
+        return None
+    _lib.check(rc, "opus_msmv_forward_sorted")
+    return out, workspace
+
+
 def backward_workspace_bytes(feats, loc, w, flags=0):
     """Device scratch the backward needs for these tensors (0 for the atomic algorithm)."""
     L, B, C, N, Q, P, _ = _check_inputs(feats, loc, w)
@@ -242,17 +287,22 @@ def msmv_dfeat_multi(grad_outs, workspaces, feats, Q, P, dfeats, rows=None, accu
     _lib.check(rc, "opus_msmv_dfeat_multi")
 
 
-def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None, out_dfeats=None):
+def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None, out_dfeats=None, sorted_ws=None):
     """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them;
-    ``out_dfeats`` given => overwrite those buffers instead of allocating new ones."""
+    ``out_dfeats`` given => overwrite those buffers instead of allocating new ones; ``sorted_ws``:
+    the workspace msmv_forward_sorted left for these loc / weights (owner algorithm, sort skipped)."""
     flags = _BWD_ALGOS[_bwd_algo if algo is None else algo]
+    if sorted_ws is not None:
+        flags = _lib.BWD_OWNER | _lib.BWD_PRESORTED
     if dfeats is None:
         dfeats = out_dfeats if out_dfeats is not None else [torch.empty_like(f) for f in feats]
     else:
         flags |= _lib.BWD_ACCUMULATE
     dloc = torch.empty_like(loc)
     dw = torch.empty_like(w)
-    msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, flags=flags, rows=rows)
+    if sorted_ws is not None and (grad_out.data_ptr() % 16 or any(d.data_ptr() % 16 for d in dfeats)):
+        sorted_ws, flags = None, (flags & _lib.BWD_ACCUMULATE) | _BWD_ALGOS[_bwd_algo if algo is None else algo]
+    msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=sorted_ws, flags=flags, rows=rows)
     return dfeats, dloc, dw
 
 
@@ -263,13 +313,19 @@ class _MSMVSampling(torch.autograd.Function):
     def forward(ctx, *args):
         *feats, sampling_locations, scale_weights = args
         ctx.save_for_backward(*feats, sampling_locations, scale_weights)
+        ctx.sorted_ws = None
+        if _fwd_sorted and _bwd_algo != "atomic":
+            res = msmv_forward_sorted(feats, sampling_locations, scale_weights)
+            if res is not None:
+                out, ctx.sorted_ws = res
+                return out
         return msmv_forward(feats, sampling_locations, scale_weights)
 
     @staticmethod
     def backward(ctx, grad_output):
         *feats, sampling_locations, scale_weights = ctx.saved_tensors
         dfeats, dloc, dw = msmv_backward(grad_output.contiguous(), feats,
-                                         sampling_locations, scale_weights)
+                                         sampling_locations, scale_weights, sorted_ws=ctx.sorted_ws)
         return (*dfeats, dloc, dw)
 
 
@@ -297,13 +353,20 @@ class MSMVSamplingRows(torch.autograd.Function):
         *feats, sampling_locations, scale_weights = args
         ctx.save_for_backward(*feats, sampling_locations, scale_weights)
         ctx.rows = (T, G)
+        ctx.sorted_ws = None
+        if _fwd_sorted and _bwd_algo != "atomic":
+            res = msmv_forward_sorted(feats, sampling_locations, scale_weights, rows=ctx.rows)
+            if res is not None:
+                out, ctx.sorted_ws = res
+                return out
         return msmv_forward(feats, sampling_locations, scale_weights, rows=ctx.rows)
 
     @staticmethod
     def backward(ctx, grad_output):
         *feats, sampling_locations, scale_weights = ctx.saved_tensors
         dfeats, dloc, dw = msmv_backward(grad_output.contiguous(), feats,
-                                         sampling_locations, scale_weights, rows=ctx.rows)
+                                         sampling_locations, scale_weights, rows=ctx.rows,
+                                         sorted_ws=ctx.sorted_ws)
         return (None, None, *dfeats, dloc, dw)
 
 
@@ -396,6 +459,12 @@ class _MSMVSamplingSink(torch.autograd.Function):
     def forward(ctx, sink, rows, token, sampling_locations, scale_weights):
         ctx.sink, ctx.rows = sink, rows
         ctx.save_for_backward(sampling_locations, scale_weights)
+        ctx.sorted_ws = None
+        if _fwd_sorted and _bwd_algo != "atomic":
+            res = msmv_forward_sorted(sink.feats, sampling_locations, scale_weights, rows=rows)
+            if res is not None:
+                out, ctx.sorted_ws = res
+                return out
         return msmv_forward(sink.feats, sampling_locations, scale_weights, rows=rows)
 
     @staticmethod
@@ -407,9 +476,13 @@ class _MSMVSamplingSink(torch.autograd.Function):
             g = grad_output.contiguous()
             if g.data_ptr() % 16:               # (a contiguous view at an odd offset)
                 g = g.clone()
-            flags = _lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER
-            need = backward_workspace_bytes(sink.feats, sampling_locations, scale_weights, flags)
-            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=g.device)
+            if ctx.sorted_ws is not None:       # the forward's sort: only the gather is left to do here
+                flags = _lib.BWD_OWNER | _lib.BWD_PRESORTED | _lib.BWD_STAGE_GATHER
+                ws = ctx.sorted_ws
+            else:
+                flags = _lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER
+                need = backward_workspace_bytes(sink.feats, sampling_locations, scale_weights, flags)
+                ws = torch.empty(max(need, 16), dtype=torch.uint8, device=g.device)
             dloc, dw = torch.empty_like(sampling_locations), torch.empty_like(scale_weights)
             msmv_backward_into(g, sink.feats, sampling_locations, scale_weights, None, dloc, dw,
                                workspace=ws, flags=flags, rows=ctx.rows)
@@ -421,7 +494,7 @@ class _MSMVSamplingSink(torch.autograd.Function):
             sink.buffers = [torch.empty_like(f) for f in sink.feats]
         _, dloc, dw = msmv_backward(grad_output.contiguous(), sink.feats, sampling_locations, scale_weights,
                                     dfeats=None if first else sink.buffers, rows=ctx.rows,
-                                    out_dfeats=sink.buffers if first else None)
+                                    out_dfeats=sink.buffers if first else None, sorted_ws=ctx.sorted_ws)
         return None, None, grad_output.new_zeros(()), dloc, dw
 
 

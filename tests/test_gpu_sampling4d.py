@@ -637,3 +637,102 @@ def test_feature_grad_sink_with_more_views_than_the_sort_takes(ops):
 
     for i, (a, b) in enumerate(zip(run(True), run(False))):
         assert_close(a.grad.cpu().numpy(), b.grad.cpu().numpy(), GRAD_RTOL, f"dfeat{i}, 17 views")
+
+
+SORTED_FWD_CASES = [
+    # Bs, T, G, Q, P, levels, oob
+    (1, 2, 2, 37, 2, REAL_LEVELS, 0.25),
+    (2, 3, 1, 300, 4, REAL_LEVELS, 0.25),          # slabs of 1200 points
+    (1, 8, 4, 450, 8, REAL_LEVELS, 0.4),           # slabs of 3600 points: the two-pass sort
+    (1, 2, 2, 19, 3, REAL_LEVELS + [(4, 11)], 0.25),
+    (1, 1, 3, 0, 2, REAL_LEVELS, 0.0),
+]
+
+
+@pytest.mark.parametrize("case", SORTED_FWD_CASES, ids=lambda c: "Bs%dT%dG%dQ%dP%dL%d" % (*c[:5], len(c[5])))
+def test_bin_ordered_forward_is_bit_identical_and_its_sort_serves_the_backward(ops, case):
+    """opus_msmv_forward_sorted against opus_msmv_forward_rows on the same inputs (same arithmetic
+    per point: equal bit for bit), incl. points with no valid view (zero rows written by the sort),
+    out-of-range locations, a re-run on the kept sort (PRESORTED), and the backward on that sort
+    (OPUS_MSMV_BWD_PRESORTED) against the backward that sorts for itself."""
+    from opus_amd import _lib
+    from opus_amd.csrc import wrapper as wr
+    Bs, T, G, Q, P, levels, oob = case
+    B, N, C = Bs * T * G, 6, 64
+    feats, loc, w, _ = random_case(900 + Q, levels, B, N, C, max(Q, 1), P, oob)
+    loc, w = loc[:, :Q], w[:, :Q]
+    if Q:
+        loc[0, 0, 0, 2] = 1.7            # no such view
+        loc[-1, Q // 2, -1, 2] = float("nan")
+    f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
+    want = wr.msmv_forward(f, l, ww, rows=(T, G))
+    res = wr.msmv_forward_sorted(f, l, ww, rows=(T, G))
+    assert res is not None
+    out, ws = res
+    assert torch.equal(out, want)
+    out2, _ = wr.msmv_forward_sorted(f, l, ww, rows=(T, G), workspace=ws, presorted=True)
+    assert torch.equal(out2, want)
+    gout = dev(np.random.default_rng(5).standard_normal(tuple(want.shape)).astype(np.float32))
+    df_ref, dl_ref, dw_ref = wr.msmv_backward(gout, f, l, ww, algo="owner", rows=(T, G))
+    df, dl, dw_ = wr.msmv_backward(gout, f, l, ww, rows=(T, G), sorted_ws=ws)
+    for i, (a, b) in enumerate(zip(df, df_ref)):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-5, f"dfeat{i} on the forward's sort")
+    assert torch.equal(dl, dl_ref) and torch.equal(dw_, dw_ref)
+    # the deferred form: gather alone on the kept sort
+    if Q:
+        dl2, dw2 = torch.full_like(l, float("nan")), torch.full_like(ww, float("nan"))
+        wr.msmv_backward_into(gout, f, l, ww, None, dl2, dw2, workspace=ws,
+                              flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED | _lib.BWD_STAGE_GATHER, rows=(T, G))
+        assert torch.equal(dl2, dl_ref) and torch.equal(dw2, dw_ref)
+
+
+def test_bin_ordered_forward_plain_layout_and_refusals(ops):
+    from opus_amd import _lib
+    from opus_amd.csrc import wrapper as wr
+    feats, loc, w, gout = random_case(950, REAL_LEVELS, 3, 6, 64, 700, 1, 0.25)
+    f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
+    out, ws = wr.msmv_forward_sorted(f, l, ww)                      # [B,Q,C,1]: a point's channels are contiguous
+    assert torch.equal(out, wr.msmv_forward(f, l, ww))
+    # through autograd: the Function keeps the sort for its backward
+    fa = [x.clone().requires_grad_(True) for x in f]
+    la, wa = l.clone().requires_grad_(True), ww.clone().requires_grad_(True)
+    o = wr.msmv_sampling(fa, la, wa)
+    o.backward(dev(gout))
+    df_ref, dl_ref, dw_ref = wr.msmv_backward(dev(gout), f, l, ww, algo="owner")
+    assert torch.equal(la.grad, dl_ref) and torch.equal(wa.grad, dw_ref)
+    for a, b in zip(fa, df_ref):
+        assert_close(a.grad.cpu().numpy(), b.cpu().numpy(), 1e-5, "d feat through autograd")
+    # P > 1 in the [B,Q,C,P] layout, C != 64: not taken (None -> the caller runs the plain forward)
+    feats2, loc2, w2, _ = random_case(951, REAL_LEVELS, 2, 6, 64, 30, 2)
+    assert wr.msmv_forward_sorted([dev(x) for x in feats2], dev(loc2), dev(w2)) is None
+    feats3, loc3, w3, _ = random_case(952, TINY_LEVELS, 2, 6, 8, 30, 1)
+    assert wr.msmv_forward_sorted([dev(x) for x in feats3], dev(loc3), dev(w3)) is None
+    # flag checks of the C entry points
+    lib = _lib.load()
+    hw = _lib.int_array([d for h_w in REAL_LEVELS for d in h_w])
+    fp = _lib.ptr_array([x.data_ptr() for x in f])
+    args = (4, fp, hw, l.data_ptr(), ww.data_ptr(), 3, 0, 0, 64, 6, 700, 1, out.data_ptr(), ws.data_ptr())
+    assert lib.opus_msmv_forward_sorted(*args, ws.numel(), 0x8, None) == -7          # unknown flag
+    assert lib.opus_msmv_forward_sorted(*args, 16, 0, None) == -6                    # workspace too small
+    dl, dw_ = torch.empty_like(l), torch.empty_like(ww)
+    with pytest.raises(RuntimeError, match="flag"):                                  # PRESORTED + STAGE_BIN
+        wr.msmv_backward_into(dev(gout), f, l, ww, None, dl, dw_, workspace=ws,
+                              flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED | _lib.BWD_STAGE_BIN)
+    with pytest.raises(RuntimeError, match="flag"):                                  # PRESORTED needs the owner algorithm
+        wr.msmv_backward_into(dev(gout), f, l, ww, [torch.empty_like(x) for x in f], dl, dw_, workspace=ws,
+                              flags=_lib.BWD_ATOMIC | _lib.BWD_PRESORTED)
+
+
+def test_bin_ordered_forward_full_size(ops):
+    """OPUS-L caller shape in row mode: equal to the input-order forward bit for bit."""
+    from opus_amd.csrc import wrapper as wr
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    Bs, T, G, Q, P, N, C = 1, 8, 4, 4800, 2, 6, 64
+    B = Bs * T * G
+    f = [torch.randn((B, N, h, w_, C), generator=gen, device="cuda") for h, w_ in REAL_LEVELS]
+    xy = torch.rand((B, Q, P, 2), generator=gen, device="cuda") * 1.2 - 0.1
+    view = torch.randint(0, N, (B, Q, P, 1), generator=gen, device="cuda").float() / (N - 1)
+    l = torch.cat([xy, view], -1).contiguous()
+    ww = torch.softmax(torch.randn((B, Q, P, 4), generator=gen, device="cuda"), -1)
+    out, _ = wr.msmv_forward_sorted(f, l, ww, rows=(T, G))
+    assert torch.equal(out, wr.msmv_forward(f, l, ww, rows=(T, G)))

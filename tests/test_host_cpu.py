@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == sorted(_lib.SYMBOLS), "ctypes table and header disagree"
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.opus_msmv_version() == 100
+    assert lib.opus_msmv_version() == 200
     assert lib.opus_msmv_strerror(0) == b"ok"
     assert b"num_point exceed limits" in lib.opus_msmv_strerror(-2)
     assert lib.opus_msmv_strerror(-99) == b"unknown error code"
