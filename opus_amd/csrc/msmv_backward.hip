@@ -569,9 +569,18 @@ struct OwnHit {
 #ifdef MSMV_DBG_TIMES
 // development aid: per-wave phase timestamps (100 MHz constant clock) of the d-feat kernel
 __device__ unsigned long long *msmv_dbg_buf;
+#ifdef MSMV_DBG_HDR
+// header study (tools/hdr_probe.py): stamps 1, 2 = level known, level geometry in; 3, 4 = bins
+// known, first entries in
+#define MSMV_DBG_STAMP(K) if ((K) == 1) dbg_t[3] = __builtin_amdgcn_s_memrealtime(); else if ((K) == 2) dbg_t[4] = __builtin_amdgcn_s_memrealtime(); else if ((K) == 5) dbg_t[5] = __builtin_amdgcn_s_memrealtime();
+#define MSMV_DBG_HSTAMP(K) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_t[K] = __builtin_amdgcn_s_memrealtime(); }
+#else
 #define MSMV_DBG_STAMP(K) if (lane == 0) dbg_t[K] = __builtin_amdgcn_s_memrealtime();
+#define MSMV_DBG_HSTAMP(K)
+#endif
 #else
 #define MSMV_DBG_STAMP(K)
+#define MSMV_DBG_HSTAMP(K)
 #endif
 
 template <int PT, bool ACC, bool MULTI>
@@ -581,6 +590,10 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
 #ifdef MSMV_DBG_TIMES
     unsigned long long dbg_t[6] = {};
     dbg_t[0] = __builtin_amdgcn_s_memrealtime();
+    unsigned dbg_hw, dbg_xcc;            // where the wave runs: HW_ID (wave, SIMD, CU, SH, SE) and the XCC
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(dbg_hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(dbg_xcc));
+    const unsigned long long dbg_where = ((unsigned long long)((dbg_xcc & 0xF) << 16 | (dbg_hw & 0xFFFF))) << 40;
 #endif
     // STAGED (P in {1,2,4} and row mode): the gradient rows of a whole queue of hits are copied
     // global -> LDS by direct loads (no VGPR destination), all in flight at once, and read from
@@ -636,6 +649,11 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         seg_start = past ? geo.seg_end[j] : seg_start;
     }
     const int l = geo.L - 1 - k;
+    MSMV_DBG_HSTAMP(1)
+#ifdef MSMV_ABL_LEVELS
+    if (!((MSMV_ABL_LEVELS >> l) & 1))       // development aid: only the levels of the mask are worked on
+        return;
+#endif
     id -= seg_start;
     const OwnerLevel G = geo.lv[l];
     const int N = geo.N;
@@ -652,6 +670,7 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
     const int prow = (int)msmv_div((uint32_t)patch, G.div_cols);
     const int r0 = prow * PATCH_H, c0 = (patch - prow * G.patch_cols) * PATCH_W;
     const int nrow = min(PATCH_H, H - r0), ncol = min(PATCH_W, W - c0);
+    MSMV_DBG_HSTAMP(2)
 
     msmv_f32x16 acc0 = {}, acc1 = {};                        // channels 0..31 / 32..63
     [[maybe_unused]] bool any_hit = false;
@@ -978,7 +997,7 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         if (lane == 0 && msmv_dbg_buf) {
             unsigned long long *o = msmv_dbg_buf + ((size_t)blockIdx.x * OWN_WAVES + wave) * 8;
             o[0] = dbg_t[0]; o[1] = dbg_t[1]; o[2] = dbg_t[2]; o[3] = dbg_t[3]; o[4] = dbg_t[4]; o[5] = 0;
-            o[6] = ((unsigned long long)l << 32) | (unsigned)total;
+            o[6] = dbg_where | ((unsigned long long)l << 32) | (unsigned)total;
             o[7] = ((unsigned long long)b << 32) | ((unsigned)view << 16) | (unsigned)(idle ? 0xFFFF : sub);
         }
         return;
@@ -1067,7 +1086,7 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
     if (lane == 0 && msmv_dbg_buf) {
         unsigned long long *o = msmv_dbg_buf + ((size_t)blockIdx.x * OWN_WAVES + wave) * 8;
         o[0] = dbg_t[0]; o[1] = dbg_t[1]; o[2] = dbg_t[2]; o[3] = dbg_t[3]; o[4] = dbg_t[4]; o[5] = dbg_t[5];
-        o[6] = ((unsigned long long)l << 32) | (unsigned)total;
+        o[6] = dbg_where | ((unsigned long long)l << 32) | (unsigned)total;
         o[7] = ((unsigned long long)b << 32) | ((unsigned)view << 16) | (unsigned)sub;
     }
 #endif

@@ -41,7 +41,11 @@ torch.cuda.synchronize()
 print("kernel (event) us:", a.elapsed_time(b) * 1e3)
 t = buf.cpu().numpy()
 t = t[t[:, 0] != 0]
-lvl = (t[:, 6] >> 32).astype(int)
+lvl = ((t[:, 6] >> 32) & 0xFF).astype(int)
+where = (t[:, 6] >> 40).astype(int)          # xcc << 16 | HW_ID
+xcc = (where >> 16) & 0xF
+cu_key = (xcc << 8) | ((where >> 8) & 0xFF)  # XCC, SE, SH, CU
+simd_key = (cu_key << 2) | ((where >> 4) & 3)
 total = (t[:, 6] & 0xFFFFFFFF).astype(int)
 bslab = (t[:, 7] >> 32).astype(int)
 sub = (t[:, 7] & 0xFFFF).astype(int)
@@ -65,3 +69,13 @@ for lo in edges:
     res = [(((T[:, 0] < hi) & (end > lo)) & (lvl == l)).sum() for l in range(4)]
     drain = ((t[:, 5] != 0) & (T[:, 4] < hi) & (T[:, 5] > lo)).sum()
     print(f"{lo:6.0f}   {res}   | {drain}")
+
+# instantaneous residency: waves alive at sample times, chip-wide and per CU / SIMD
+print("CUs seen", len(np.unique(cu_key)), "SIMDs seen", len(np.unique(simd_key)))
+print("t(us)  resident  [L0 L1 L2 L3]  per-CU min/median/max  per-SIMD max  CUs with < 8 waves")
+for ts in np.arange(2.5, end.max(), 5.0):
+    alive = (T[:, 0] <= ts) & (end > ts)
+    per_cu = np.bincount(np.unique(cu_key, return_inverse=True)[1][alive], minlength=len(np.unique(cu_key)))
+    per_simd = np.bincount(np.unique(simd_key, return_inverse=True)[1][alive], minlength=len(np.unique(simd_key)))
+    print(f"{ts:6.1f} {alive.sum():7d}  {[int((alive & (lvl == l)).sum()) for l in range(4)]}  "
+          f"{per_cu.min()}/{int(np.median(per_cu))}/{per_cu.max()}  {per_simd.max()}  {(per_cu < 8).sum()}")

@@ -76,6 +76,30 @@ __global__ void __launch_bounds__(256) fill_patch_x4(float *dst)
     }
 }
 
+// 1 x 32 pixels per wave (8 KiB contiguous), the 4 waves of a workgroup stacked vertically: the
+// workgroup covers 4 rows x 32 pixels like four 4 x 8 patches side by side, but each wave writes
+// one row of it (what exchanging the accumulators between the waves through LDS would allow)
+template <bool NT>
+__global__ void __launch_bounds__(256) fill_rows_of_wg(float *dst)
+{
+    const int lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    constexpr int PCOLS = W / 32, PROWS = H / 4, TILES = PCOLS * PROWS;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3, q = gridDim.x >> 3;
+    const int id = xcd * q + within;
+    const int slab = id / TILES, tile = id % TILES;
+    const int trow = tile / PCOLS, tcol = tile % PCOLS;
+    float *base = dst + ((size_t)slab * H * W + (size_t)(trow * 4 + wave) * W + tcol * 32) * 64;
+    const float v = (float)lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float *o = base + (size_t)(r * 2 + half) * 64 + l32;
+        st<NT>(o, v);
+        st<NT>(o + 32, v);
+    }
+}
+
 template <typename F> float time_it(F f, int reps = 20)
 {
     hipEvent_t a, b;
@@ -95,7 +119,7 @@ int main()
     const size_t bytes = (size_t)SLABS * H * W * 256;
     float *d; hipMalloc(&d, bytes);
     const size_t n4 = bytes / 16;
-    auto rep = [&](const char *name, float us) { printf("%-28s %8.1f us  %6.2f TB/s\n", name, us, bytes / us / 1e6); };
+    auto rep = [&](const char *name, float us) { printf("%-42s %8.1f us  %6.2f TB/s\n", name, us, bytes / us / 1e6); };
     rep("sequential plain", time_it([&] { fill_seq<false><<<(unsigned)((n4 + 255) / 256), 256>>>(d, n4); }));
     rep("sequential nt", time_it([&] { fill_seq<true><<<(unsigned)((n4 + 255) / 256), 256>>>(d, n4); }));
 #define PATCH(PH, PW)                                                                                  \
@@ -109,6 +133,8 @@ int main()
     rep("patch " #PH "x" #PW " 16B/lane nt", time_it([&] { fill_patch_x4<PH, PW, true><<<SLABS * (H / PH) * (W / PW) / 4, 256>>>(d); }));
     PATCH4(4, 8)
     PATCH4(2, 16)
+    rep("4 rows x 32 px per WG, wave = row plain", time_it([&] { fill_rows_of_wg<false><<<SLABS * (H / 4) * (W / 32), 256>>>(d); }));
+    rep("4 rows x 32 px per WG, wave = row nt", time_it([&] { fill_rows_of_wg<true><<<SLABS * (H / 4) * (W / 32), 256>>>(d); }));
     hipError_t e = hipDeviceSynchronize();
     printf("%s\n", hipGetErrorString(e));
     return 0;
