@@ -140,7 +140,7 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
  * offsets and the sorted point entries, opus_msmv_backward_workspace_bytes() bytes) lives in a
  * static device array of OPUS_MSMV_NOALLOC_SCRATCH_BYTES inside the library, one copy per GPU,
  * held until the process ends.  Sizes that need more return OPUS_MSMV_ESCRATCH (32 MiB covers
- * B*Q*P <= about 1.0 M points at N = 6, e.g. three OPUS-L samples); nothing is launched then.
+ * B*Q*P <= about 0.85 M points at N = 6, e.g. two OPUS-L samples); nothing is launched then.
  * The call neither allocates nor frees nor synchronises.  The first call on a device looks the
  * array's address up (hipGetSymbolAddress, which may load the library's code object): make it
  * outside any graph capture.  All calls on one GPU share that GPU's array: calls that overlap

@@ -129,34 +129,42 @@ constexpr int BIN_PER_VIEW = BIN_YB * BIN_XB;
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_MAX_KEYS = 4096;       // N * BIN_PER_VIEW must not exceed this (N <= 16)
 
+constexpr int BIN_MAX_CHUNKS = 16;       // binning workgroups per batch slab, at most
+
 // workspace layout:
-//   [ counts: B*keys ints ][ cursors: B*keys ints ][ tails: B ints ]   cleared by a memset node every call
+//   [ table: B * chunks * (keys+1) ints ]   per binning workgroup: its points per key, and in the
+//                                            last column its points without a valid view
 //   [ offsets: B*(keys+1) ints ]  (padded to 256 B)   exclusive prefix of the counts per batch
 //   [ entries: npts * 32 B ]
 // entries of batch b occupy [b*QP, b*QP + offsets[b][keys]), sorted by
-// key = (view*BIN_YB + yband)*BIN_XB + xband (order inside a key is arbitrary).  The slab's other
-// slots, [b*QP + offsets[b][keys], (b+1)*QP), hold its points without a valid view (in no bin, view
-// -1 in the entry): the d-feat pass, which walks bins, never meets them; the passes that walk all
-// QP slots of a slab (gather, bin-ordered forward) write their all-zero results.  The sort thus
-// reads loc and weights only, and one sort serves forward and backward passes alike.
+// key = (view*BIN_YB + yband)*BIN_XB + xband (inside a key: by binning workgroup, i.e. by blocks of
+// consecutive points).  The slab's other slots, [b*QP + offsets[b][keys], (b+1)*QP), hold its points
+// without a valid view (in no bin, view -1 in the entry): the d-feat pass, which walks bins, never
+// meets them; the passes that walk all QP slots of a slab (gather, bin-ordered forward) write their
+// all-zero results.  The sort thus reads loc and weights only, and one sort serves forward and
+// backward passes alike.  Nothing in the workspace needs clearing: every word that is read was
+// written by the same sort.
 struct OwnerWs {
-    int *counts;
-    int *cursors;
-    int *tails;           // per slab: points without a valid view placed so far (filled from the slab's last slot down)
+    int *table;
     int *offsets;
     BinEntry *entries;
     int keys;             // N * BIN_PER_VIEW
-    int chunks;           // binning workgroups per batch slab
+    int chunks;           // binning workgroups per batch slab (<= BIN_MAX_CHUNKS)
+    int chunk_pts;        // points per binning workgroup
 };
 
-__host__ __device__ inline size_t owner_ws_clear_bytes(int B, int N)
+// Slabs of more than BIN_MAX_CHUNKS * BIN_THREADS points give each workgroup several rounds of
+// BIN_THREADS points instead of more workgroups: the table stays small against the entries.
+__host__ __device__ inline int owner_ws_chunks(int qp)
 {
-    return ((size_t)B * N * BIN_PER_VIEW * 2 + (size_t)B) * sizeof(int);
+    const int c = (qp + BIN_THREADS - 1) / BIN_THREADS;
+    return c < 1 ? 1 : (c > BIN_MAX_CHUNKS ? BIN_MAX_CHUNKS : c);
 }
 
-__host__ __device__ inline size_t owner_ws_header_bytes(int B, int N)
+__host__ __device__ inline size_t owner_ws_header_bytes(int B, int N, int qp)
 {
-    const size_t h = owner_ws_clear_bytes(B, N) + (size_t)B * (N * BIN_PER_VIEW + 1) * sizeof(int);
+    const size_t keys1 = (size_t)N * BIN_PER_VIEW + 1;
+    const size_t h = ((size_t)B * owner_ws_chunks(qp) * keys1 + (size_t)B * keys1) * sizeof(int);
     return (h + 255) & ~(size_t)255;
 }
 
@@ -197,21 +205,31 @@ __device__ __forceinline__ void msmv_band_range(int lo, int hi, int size, MsmvDi
     }
 }
 
-// The entry of point pt (location x, y, bin key or -1) at slot `pos` of its slab.
-__device__ __forceinline__ void msmv_put_entry(const MsmvArgs &a, const OwnerWs &ws, int b, int pos, size_t pt,
-                                               float x, float y, int key)
+// The scale weights of point pt, padded to the entry's five slots.
+struct BinWeights {
+    float w[5];
+};
+
+__device__ __forceinline__ BinWeights msmv_load_weights(const MsmvArgs &a, size_t pt)
 {
     const float *wp = a.w + pt * a.L;
-    float wv[5];
+    BinWeights r;
 #pragma unroll
     for (int k = 0; k < 5; ++k)
-        wv[k] = k < a.L ? wp[k] : 0.f;
+        r.w[k] = k < a.L ? wp[k] : 0.f;
+    return r;
+}
+
+// The entry of point pt (location x, y, weights, bin key or -1) at slot `pos` of its slab.
+__device__ __forceinline__ void msmv_put_entry(const MsmvArgs &a, const OwnerWs &ws, int b, int pos, size_t pt,
+                                               float x, float y, BinWeights wv, int key)
+{
     if (a.L <= 4)
-        wv[4] = __int_as_float(key < 0 ? -1 : key / BIN_PER_VIEW);     // the view, for the passes that walk the slots
+        wv.w[4] = __int_as_float(key < 0 ? -1 : key / BIN_PER_VIEW);   // the view, for the passes that walk the slots
     float4 *e = reinterpret_cast<float4 *>(ws.entries + (size_t)b * a.qp + pos);
     const int id = a.rows ? msmv_row_of((int)pt, a) : (int)pt;
-    e[0] = make_float4(__int_as_float(id), x, y, wv[0]);
-    e[1] = make_float4(wv[1], wv[2], wv[3], wv[4]);
+    e[0] = make_float4(__int_as_float(id), x, y, wv.w[0]);
+    e[1] = make_float4(wv.w[1], wv.w[2], wv.w[3], wv.w[4]);
 }
 
 __device__ __forceinline__ int msmv_bin_key(const float *lp, int N)
@@ -258,68 +276,71 @@ __device__ __forceinline__ void msmv_block_scan(int *v, int keys, int *wave_tot)
     __syncthreads();
 }
 
-// Counting sort of the points of every batch slab by key, in two short launches with one
-// point per thread and BIN_THREADS points per workgroup.
-// Pass 1: per-workgroup LDS histogram, then one global add per non-empty key.
+// Counting sort of the points of every batch slab by key, in two short launches; a slab is cut
+// into `chunks` runs of consecutive points, one workgroup each.  No global atomics and nothing to
+// clear: pass 1 writes every workgroup's histogram to the table, pass 2 reads the slab's rows of it.
+// Pass 1: per-workgroup LDS histogram -> table[b][chunk][0..keys], last column = points in no bin.
 __global__ void __launch_bounds__(BIN_THREADS)
 msmv_bin_count(const MsmvArgs a, OwnerWs ws)
 {
-    __shared__ int hist[BIN_MAX_KEYS];
+    __shared__ int hist[BIN_MAX_KEYS + 1];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / ws.chunks, i = (blockIdx.x % ws.chunks) * BIN_THREADS + tid;
+    const int b = blockIdx.x / ws.chunks, chunk = blockIdx.x % ws.chunks;
     const int keys = ws.keys;
-    for (int k = tid; k < keys; k += BIN_THREADS)
+    for (int k = tid; k <= keys; k += BIN_THREADS)
         hist[k] = 0;
     __syncthreads();
-    if (i < a.qp) {
+    const int lo = chunk * ws.chunk_pts, hi = min(lo + ws.chunk_pts, a.qp);
+    for (int i = lo + tid; i < hi; i += BIN_THREADS) {
         const int key = msmv_bin_key(a.loc + ((size_t)b * a.qp + i) * 3, a.N);
-        if (key >= 0)
-            atomicAdd(&hist[key], 1);
+        atomicAdd(&hist[key >= 0 ? key : keys], 1);
     }
     __syncthreads();
-    for (int k = tid; k < keys; k += BIN_THREADS)
-        if (hist[k])
-            atomicAdd(ws.counts + (size_t)b * keys + k, hist[k]);
+    int *row = ws.table + ((size_t)b * ws.chunks + chunk) * (keys + 1);
+    for (int k = tid; k <= keys; k += BIN_THREADS)
+        row[k] = hist[k];
 }
 
-// Pass 2: every workgroup rebuilds the slab's exclusive prefix from the global counts,
-// claims a range per key with one global add, and places its points.
+// Pass 2: every workgroup sums the slab's table rows - all of them for the slab's counts per key,
+// those of the workgroups before it for where its own points of a key begin - scans the counts,
+// and places its points (LDS cursors).
 __global__ void __launch_bounds__(BIN_THREADS)
 msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
 {
-    __shared__ int hist[BIN_MAX_KEYS];        // local counts, then the claimed base per key
+    __shared__ int base[BIN_MAX_KEYS + 1];    // points of the key placed by earlier workgroups, then the next free slot
     __shared__ int incl[BIN_MAX_KEYS];        // the slab's counts, then their inclusive prefix
     __shared__ int wave_tot[BIN_THREADS / 64];
-    __shared__ int tail_n;                    // this workgroup's points without a valid view, then their base
     const int tid = threadIdx.x;
     const int b = blockIdx.x / ws.chunks, chunk = blockIdx.x % ws.chunks;
-    const int i = chunk * BIN_THREADS + tid;
     const int keys = ws.keys;
-    const size_t pt = (size_t)b * a.qp + i;
 
-    for (int k = tid; k < keys; k += BIN_THREADS) {
-        hist[k] = 0;
-        incl[k] = ws.counts[(size_t)b * keys + k];
+    // this workgroup's points: location loads in flight while the table is summed
+    const int lo = chunk * ws.chunk_pts, hi = min(lo + ws.chunk_pts, a.qp);
+    const int i0 = lo + tid;
+    float x = 0.f, y = 0.f, v = 0.f;
+    BinWeights wv = {};
+    if (i0 < hi) {
+        const float *lp = a.loc + ((size_t)b * a.qp + i0) * 3;
+        x = lp[0]; y = lp[1]; v = lp[2];
+        wv = msmv_load_weights(a, (size_t)b * a.qp + i0);
     }
-    if (tid == 0)
-        tail_n = 0;
+    const int *rows = ws.table + (size_t)b * ws.chunks * (keys + 1);
+    for (int k = tid; k <= keys; k += BIN_THREADS) {
+        int all = 0, before = 0;
+        for (int c = 0; c < ws.chunks; ++c) {
+            const int n = rows[(size_t)c * (keys + 1) + k];
+            all += n;
+            before += c < chunk ? n : 0;
+        }
+        base[k] = before;
+        if (k < keys)
+            incl[k] = all;
+    }
     __syncthreads();
-    int key = -1, rank = 0;
-    float x = 0.f, y = 0.f;
-    if (i < a.qp) {
-        const float *lp = a.loc + pt * 3;
-        x = lp[0];
-        y = lp[1];
-        key = msmv_bin_key(lp, a.N);
-        rank = atomicAdd(key >= 0 ? &hist[key] : &tail_n, 1);
-    }
-    msmv_block_scan(incl, keys, wave_tot);    // (its first barrier also orders the LDS atomics above)
-    if (tid == 0 && tail_n)
-        tail_n = atomicAdd(ws.tails + b, tail_n);
+    msmv_block_scan(incl, keys, wave_tot);
     for (int k = tid; k < keys; k += BIN_THREADS) {
-        const int n = hist[k];
-        const int excl = incl[k] - ws.counts[(size_t)b * keys + k];
-        hist[k] = excl + (n ? atomicAdd(ws.cursors + (size_t)b * keys + k, n) : 0);
+        const int excl = k ? incl[k - 1] : 0;
+        base[k] += excl;
         if (chunk == 0) {
             int *off = ws.offsets + (size_t)b * (keys + 1);
             off[k] = excl;
@@ -327,9 +348,22 @@ msmv_bin_fill(const MsmvArgs a, OwnerWs ws)
                 off[keys] = incl[k];
         }
     }
+    if (chunk == 0 && keys == 0 && tid == 0)
+        ws.offsets[(size_t)b] = 0;
     __syncthreads();
-    if (i < a.qp)
-        msmv_put_entry(a, ws, b, key >= 0 ? hist[key] + rank : a.qp - 1 - (tail_n + rank), pt, x, y, key);
+    for (int i = i0; i < hi; i += BIN_THREADS) {
+        const size_t pt = (size_t)b * a.qp + i;
+        if (i != i0) {
+            const float *lp = a.loc + pt * 3;
+            x = lp[0]; y = lp[1]; v = lp[2];
+            wv = msmv_load_weights(a, pt);
+        }
+        const float l3[3] = {x, y, v};
+        const int key = msmv_bin_key(l3, a.N);
+        const int r = atomicAdd(&base[key >= 0 ? key : keys], 1);
+        // (points in no bin fill the slab's slots from the last one down)
+        msmv_put_entry(a, ws, b, key >= 0 ? r : a.qp - 1 - r, pt, x, y, wv, key);
+    }
 }
 
 // Small slabs (at most BIN_ONE_PPT * BIN_THREADS points, e.g. OPUS-T / S): the whole counting
@@ -389,7 +423,7 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
         const size_t pt = (size_t)b * a.qp + i;
         if (i < a.qp) {
             const int pos = key[u] >= 0 ? incl[key[u]] - hist[key[u]] + rank[u] : a.qp - 1 - rank[u];
-            msmv_put_entry(a, ws, b, pos, pt, x[u], y[u], key[u]);
+            msmv_put_entry(a, ws, b, pos, pt, x[u], y[u], msmv_load_weights(a, pt), key[u]);
         }
     }
 }
@@ -1390,7 +1424,7 @@ bool msmv_backward_owner_supported(const MsmvArgs &a)
 
 size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
 {
-    return owner_ws_header_bytes(B, N) + (size_t)B * Q * P * sizeof(BinEntry);
+    return owner_ws_header_bytes(B, N, Q * P) + (size_t)B * Q * P * sizeof(BinEntry);
 }
 
 template <bool ACC, bool MULTI>
@@ -1408,12 +1442,12 @@ static OwnerWs owner_ws_of(const MsmvArgs &a, void *workspace)
 {
     OwnerWs ws;
     ws.keys = a.N * BIN_PER_VIEW;
-    ws.chunks = (a.qp + BIN_THREADS - 1) / BIN_THREADS;
-    ws.counts = reinterpret_cast<int *>(workspace);
-    ws.cursors = ws.counts + (size_t)a.B * ws.keys;
-    ws.tails = ws.cursors + (size_t)a.B * ws.keys;
-    ws.offsets = ws.tails + a.B;
-    ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N));
+    ws.chunks = owner_ws_chunks(a.qp);
+    const int per = (a.qp + ws.chunks - 1) / ws.chunks;
+    ws.chunk_pts = per > 0 ? per : 1;
+    ws.table = reinterpret_cast<int *>(workspace);
+    ws.offsets = ws.table + (size_t)a.B * ws.chunks * (ws.keys + 1);
+    ws.entries = reinterpret_cast<BinEntry *>(reinterpret_cast<char *>(workspace) + owner_ws_header_bytes(a.B, a.N, a.qp));
     return ws;
 }
 
@@ -1503,23 +1537,17 @@ extern "C" int opus_msmv_debug_set_buffer(void *p)
 #endif
 
 // The counting sort of every batch slab's points into `workspace` (see OwnerWs).
-static hipError_t launch_sort(const MsmvArgs &a, const OwnerWs &ws, void *workspace, hipStream_t s)
+static hipError_t launch_sort(const MsmvArgs &a, const OwnerWs &ws, hipStream_t s)
 {
-    hipError_t e;
     if (a.qp > 0 && a.qp <= BIN_ONE_PPT * BIN_THREADS) {
         hipLaunchKernelGGL(msmv_bin_one, dim3((unsigned)a.B), dim3(BIN_THREADS), 0, s, a, ws);
         return hipSuccess;
     }
-    if ((e = hipMemsetAsync(workspace, 0, owner_ws_clear_bytes(a.B, a.N), s)) != hipSuccess)
-        return e;
-    if (ws.chunks > 0) {
-        const dim3 grid((unsigned)(a.B * ws.chunks)), block(BIN_THREADS);
-        hipLaunchKernelGGL(msmv_bin_count, grid, block, 0, s, a, ws);
-        hipLaunchKernelGGL(msmv_bin_fill, grid, block, 0, s, a, ws);
-        return hipSuccess;
-    }
-    // no queries: the offsets must still read as "every bin empty"
-    return hipMemsetAsync(ws.offsets, 0, (size_t)a.B * (ws.keys + 1) * sizeof(int), s);
+    // (no queries: one workgroup per slab still writes the offsets, "every bin empty")
+    const dim3 grid((unsigned)(a.B * ws.chunks)), block(BIN_THREADS);
+    hipLaunchKernelGGL(msmv_bin_count, grid, block, 0, s, a, ws);
+    hipLaunchKernelGGL(msmv_bin_fill, grid, block, 0, s, a, ws);
+    return hipSuccess;
 }
 
 hipError_t msmv_launch_forward_sorted(const MsmvArgs &a, void *workspace, hipStream_t s, bool presorted)
@@ -1527,7 +1555,7 @@ hipError_t msmv_launch_forward_sorted(const MsmvArgs &a, void *workspace, hipStr
     const OwnerWs ws = owner_ws_of(a, workspace);
     const hipError_t stale = hipPeekAtLastError();
     hipError_t e;
-    if (!presorted && (e = launch_sort(a, ws, workspace, s)) != hipSuccess)
+    if (!presorted && (e = launch_sort(a, ws, s)) != hipSuccess)
         return e;
     if (a.npts > 0) {
         const int ngroups = (a.npts + 3) / 4;
@@ -1547,7 +1575,7 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     const hipError_t stale = hipPeekAtLastError();
 
     hipError_t e;
-    if ((stages & 1) && (e = launch_sort(a, ws, workspace, s)) != hipSuccess)
+    if ((stages & 1) && (e = launch_sort(a, ws, s)) != hipSuccess)
         return e;
     if ((e = msmv_launch_status(stale)) != hipSuccess)
         return e;

@@ -272,6 +272,40 @@ def test_out_of_range_view_and_nan_location(wr, oracle):
         assert all(np.isfinite(d).all() for d in dfeats)
 
 
+@pytest.mark.parametrize("Q,P", [(700, 1), (1700, 2), (1500, 1)], ids=["one-pass sort", "two-pass sort", "P1 forward"])
+def test_slabs_with_many_points_in_no_view(wr, oracle, Q, P):
+    """Points without a valid view are the tail entries of their slab's sort: a slab where every
+    point is one, a slab where every other point is one, and an ordinary slab - zero output rows,
+    zero gradients, d feats from the valid points only, from both sort kernels (a slab of up to
+    3072 points is sorted by one workgroup, larger ones in two passes); with one point per query
+    the bin-ordered forward and a backward on its sort run over the same entries."""
+    feats, loc, w, grad_out = random_case(77 + Q, REAL_LEVELS, B=3, N=6, C=64, Q=Q, P=P)
+    loc[0, :, :, 2] = 1.4                        # no such view anywhere in slab 0
+    loc[1, ::2, :, 2] = np.nan                   # every other query of slab 1
+    grad_out[0, 0] = np.inf                      # (a gradient row nobody may read a number from)
+    ref_out = oracle.forward(feats, loc, w)
+    g_fin = grad_out.copy()
+    g_fin[0, 0] = 0.0
+    ref_df, ref_dloc, ref_dw = oracle.backward(g_fin, feats, loc, w)
+    out, dfeats, dloc, dw = run_hip(wr, feats, loc, w, grad_out, algo="owner")
+    assert_close(out, ref_out, FWD_RTOL, "forward")
+    assert (out[0] == 0).all() and (out[1, ::2] == 0).all()
+    assert (dloc[0] == 0).all() and (dw[0] == 0).all() and (dloc[1, ::2] == 0).all() and (dw[1, ::2] == 0).all()
+    for i in range(4):
+        assert (dfeats[i][0] == 0).all()
+        assert_close(dfeats[i], ref_df[i], GRAD_RTOL, f"dfeat{i}")
+    assert_close(dloc[..., :2], ref_dloc[..., :2], GRAD_RTOL, "dloc")
+    assert_close(dw, ref_dw, GRAD_RTOL, "dw")
+    if P == 1:
+        f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
+        res = wr.msmv_forward_sorted(f, l, ww)
+        assert res is not None
+        o2, ws = res
+        assert torch.equal(o2, wr.msmv_forward(f, l, ww))
+        df2, dl2, dw2 = wr.msmv_backward(dev(grad_out), f, l, ww, sorted_ws=ws)
+        assert torch.equal(dl2.cpu(), torch.from_numpy(dloc)) and torch.equal(dw2.cpu(), torch.from_numpy(dw))
+
+
 # ---------------------------------------------------------------- API behaviour
 def test_autograd_functions_and_dispatch(wr, oracle):
     feats, loc, w, grad_out = random_case(21, REAL_LEVELS, B=2, N=6, C=64, Q=10, P=2)

@@ -85,7 +85,7 @@ def test_argument_validation_returns_before_any_launch(lib):
     assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 1, null, null, null) == -4
     assert pp(null, null, null, 1, 4, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 2, null, null, null) == -7   # unknown flag
     assert pp(null, null, null, 1, 0, 8, 4, 2, 4, 6, 256.0, 704.0, 1e-5, 0, null, null, null) == 0
-    assert n >= 32 * 4800 * 2 * 32 and n < 32 * 4800 * 2 * 32 + (1 << 20)
+    assert n >= 32 * 4800 * 2 * 32 and n < 32 * 4800 * 2 * 32 + (4 << 20)
     # sort / gather stages alone need no d feats; the deferred d-feat pass validates its sets
     assert bwd(1, null, ptrs, hw, null, null, 1, 64, 6, 1, 1, None, null, null, null, 0, 0x502, null) == -4
     assert bwd(1, null, ptrs, hw, null, null, 1, 64, 6, 1, 1, None, null, null, null, 0, 0x202, null) == -4

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the bench.py lines committed under profiles/ (copied from gpurun_out/<tag>/).
-#   gpurun -- 'bash tools/collect_bench.sh r01'
+#   gpurun -- 'bash tools/collect_bench.sh r02'
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG/bench
 mkdir -p "$O"
@@ -13,8 +13,9 @@ run() { # name, args...
     echo "done $name"
 }
 run L
+run L_driver --steps 20 --warmup 5                 # the invocation the round-end driver uses
 for v in T S M; do run $v-fwdbwd --workload $v-fwdbwd --no-cpu-baseline; done
-run T-fwd --workload T-fwd --no-cpu-baseline
+run T-fwd --workload T-fwd                         # (with the CPU baseline: OPUS-T forward on the host cores)
 run L-fwd --workload L-fwd --no-cpu-baseline
 run T-fwd_batch8 --workload T-fwd --batch 8 --no-cpu-baseline
 run L_batch8 --batch 8 --steps 100 --no-cpu-baseline
@@ -25,6 +26,8 @@ run decoder-L_accumulate --workload decoder-L --dfeat accumulate --steps 100 --n
 run decoder-T --workload decoder-T --steps 100 --no-cpu-baseline
 run decoder-T_accumulate --workload decoder-T --dfeat accumulate --steps 100 --no-cpu-baseline
 run sampling4d-L --workload sampling4d-L --no-cpu-baseline
+run sampling4d-L_input-order --workload sampling4d-L --fwd-order input --no-cpu-baseline
+run train-M --workload train-M --steps 50 --no-cpu-baseline
 run sampling4d-T --workload sampling4d-T --no-cpu-baseline
 run L_graph --graph --no-cpu-baseline
 run decoder-L_graph --workload decoder-L --graph --steps 100 --no-cpu-baseline

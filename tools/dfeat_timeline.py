@@ -79,3 +79,8 @@ for ts in np.arange(2.5, end.max(), 5.0):
     per_simd = np.bincount(np.unique(simd_key, return_inverse=True)[1][alive], minlength=len(np.unique(simd_key)))
     print(f"{ts:6.1f} {alive.sum():7d}  {[int((alive & (lvl == l)).sum()) for l in range(4)]}  "
           f"{per_cu.min()}/{int(np.median(per_cu))}/{per_cu.max()}  {per_simd.max()}  {(per_cu < 8).sum()}")
+# per XCC: when its first wave starts, when its last ends, and how many waves it ran
+print("XCC  waves  first start  last end")
+for x in np.unique(xcc):
+    m = xcc == x
+    print(f"{x:3d} {m.sum():7d} {T[m, 0].min():8.1f} {end[m].max():8.1f}")

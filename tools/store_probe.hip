@@ -135,6 +135,10 @@ int main()
     PATCH4(2, 16)
     rep("4 rows x 32 px per WG, wave = row plain", time_it([&] { fill_rows_of_wg<false><<<SLABS * (H / 4) * (W / 32), 256>>>(d); }));
     rep("4 rows x 32 px per WG, wave = row nt", time_it([&] { fill_rows_of_wg<true><<<SLABS * (H / 4) * (W / 32), 256>>>(d); }));
+    // the same patch kernel with the d-feat kernel's LDS footprint per workgroup (21.5 KiB: 7 workgroups per CU)
+    rep("patch 4x8 nt + 21.5 KiB LDS/WG", time_it([&] { fill_patch<4, 8, true><<<SLABS * (H / 4) * (W / 8) / 4, 256, 21504>>>(d); }));
+    rep("patch 4x8 nt + 40 KiB LDS/WG", time_it([&] { fill_patch<4, 8, true><<<SLABS * (H / 4) * (W / 8) / 4, 256, 40960>>>(d); }));
+    rep("patch 1x32 nt + 21.5 KiB LDS/WG", time_it([&] { fill_patch<1, 32, true><<<SLABS * (H / 1) * (W / 32) / 4, 256, 21504>>>(d); }));
     hipError_t e = hipDeviceSynchronize();
     printf("%s\n", hipGetErrorString(e));
     return 0;
