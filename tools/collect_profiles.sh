@@ -7,7 +7,7 @@ TAG=${1:-r02}
 shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
-mkdir -p "$O"
+rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- \
     python3 "$R/bench.py" --no-cpu-baseline "$@" > "$O/bench_under_rocprof.json" 2> "$O/stats.err" || exit 1
