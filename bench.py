@@ -317,7 +317,8 @@ class Step:
             elif self.fwd_sorted and not record:
                 wrapper.msmv_backward_into(*args, flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED | acc, rows=rows)
             elif self.fwd_sorted:
-                for name, bit in (("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT), ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
+                # (in the order the one-call form issues them: the gather first)
+                for name, bit in (("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER), ("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT)):
                     self._timed(name if not (acc and bit == _lib.BWD_STAGE_DFEAT) else name + "(accumulate)",
                                 lambda bit=bit: wrapper.msmv_backward_into(
                                     *args, flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED | bit | acc, rows=rows), record)
@@ -331,13 +332,13 @@ class Step:
                         self._timed(name, lambda bit=bit: wrapper.msmv_backward_into(
                             *dargs, flags=_lib.BWD_OWNER | bit, rows=rows), record)
             elif self.algo == "owner" and not record:
-                # the product path: one call issues the sort, the d-feat and the gather kernels
+                # the product path: one call issues the sort, the gather and the d-feat kernels
                 wrapper.msmv_backward_into(*args, flags=_lib.BWD_OWNER | acc, rows=rows)
             elif self.algo == "owner":
                 # the same launches stage by stage, so that each kernel gets its own event pair
                 for name, bit in (("msmv_bin_sort", _lib.BWD_STAGE_BIN),
-                                  ("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT),
-                                  ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER)):
+                                  ("msmv_bwd_gather_c64", _lib.BWD_STAGE_GATHER),
+                                  ("msmv_bwd_owner_dfeat", _lib.BWD_STAGE_DFEAT)):
                     self._timed(name if not (acc and bit == _lib.BWD_STAGE_DFEAT) else name + "(accumulate)",
                                 lambda bit=bit: wrapper.msmv_backward_into(
                                     *args, flags=_lib.BWD_OWNER | bit | acc, rows=rows), record)

@@ -62,9 +62,10 @@ enum {
  * The reference always clears and lets autograd add (msmv_sampling.cpp:244-247). */
 #define OPUS_MSMV_BWD_ACCUMULATE 0x10
 /* OR-ed into `flags` (owner algorithm only): run just the named stage(s) of the backward,
- * so that a profiler or benchmark can time each kernel with events of its own.  The stages
- * must be issued in this order on one stream with the same arguments and workspace; no
- * stage bit set means all three.  `dfeats` may be NULL when STAGE_DFEAT is not among the
+ * so that a profiler or benchmark can time each kernel with events of its own.  STAGE_BIN
+ * must come first, on the same stream and with the same arguments and workspace as the other
+ * two, which are independent of each other (a call with both runs the gather first: it leaves
+ * the gradient rows in the Infinity Cache for the d-feat pass); no stage bit set means all three.  `dfeats` may be NULL when STAGE_DFEAT is not among the
  * stages asked for (see opus_msmv_dfeat_multi); `dloc` / `dweights` when STAGE_GATHER is not
  * (the sort reads `loc` and `weights` only).  No counterpart in the reference. */
 #define OPUS_MSMV_BWD_STAGE_BIN 0x100      /* sort the points into (batch, view, band) bins */

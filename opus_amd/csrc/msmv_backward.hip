@@ -1580,6 +1580,16 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
     if ((e = msmv_launch_status(stale)) != hipSuccess)
         return e;
 
+    // The gather runs BEFORE the d-feat pass: both need only the sort and write disjoint outputs, and
+    // the gather reads every gradient row anyway - it leaves them in the Infinity Cache, where the
+    // d-feat pass, whose waves are bound by the latency of exactly those rows, finds them (measured:
+    // d feat 171 -> 164 us at OPUS-L after a forward, 158 us with nothing else in between).
+    if (a.npts > 0 && (stages & 4)) {
+        if (a.L == 4)
+            launch_gather<4>(a, ws, s);
+        else
+            launch_gather<5>(a, ws, s);
+    }
     if (stages & 2) {
         OwnerSets sets = {};
         sets.n = 1;
@@ -1588,12 +1598,6 @@ hipError_t msmv_launch_backward_owner(const MsmvArgs &a, void *workspace, hipStr
         sets.entries[0] = ws.entries;
         if ((e = launch_dfeat_sets(a, sets, s, accumulate)) != hipSuccess)
             return e;
-    }
-    if (a.npts > 0 && (stages & 4)) {
-        if (a.L == 4)
-            launch_gather<4>(a, ws, s);
-        else
-            launch_gather<5>(a, ws, s);
     }
     return msmv_launch_status(stale);
 }

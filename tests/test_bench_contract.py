@@ -21,6 +21,16 @@ def run_bench(*args, timeout=300):
     return json.loads(lines[0])
 
 
+def test_traffic_of_another_configuration_is_null_not_borrowed():
+    """A PMC figure is keyed by workload, batch and point distribution: anything else reads as None."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.load_traffic("T-fwdbwd", 1, "uniform", "msmv_bwd_owner_dfeat")["bytes"] > 0
+    assert bench.load_traffic("T-fwdbwd", 8, "uniform", "msmv_bwd_owner_dfeat") is None
+    assert bench.load_traffic("T-fwdbwd", 1, "cameras", "msmv_bwd_owner_dfeat") is None
+    assert bench.load_traffic("T-fwdbwd", 1, "uniform", "no_such_kernel") is None
+
+
 def test_help_lists_the_contract_flags():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], cwd=ROOT,
                        capture_output=True, text=True, timeout=120)
@@ -47,8 +57,11 @@ def test_result_line_carries_every_contract_field():
     assert roof["frac"] <= 1.0 and roof["achieved_alg"] >= roof["achieved"]
     k = r["kernels"][roof["kernel"]]
     assert abs(roof["achieved"] - k["compulsory_bytes"] / (k["avg_us"] * 1e-6) / 1e9) <= 1e-6 * roof["achieved"]
-    # no PMC pass of this configuration (OPUS-T, 4 steps) is committed: null, not a borrowed figure
-    assert "traffic" in roof and roof["traffic"] is None
+    # traffic: the committed PMC pass of exactly this workload | batch | points (profiles/traffic.json)
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        rec = json.load(f)["T-fwdbwd|batch=1|points=uniform"][roof["kernel"]]
+    assert roof["traffic"] == rec["bytes"] and rec["template"].startswith(roof["kernel"])
+    assert roof["traffic"] <= 1.1 * k["compulsory_bytes"], "the dominant kernel moves what it must, not more"
     # the whole-pass algorithmic bytes are the contract's: 4380 B/point forward, 8504 B/point + F backward
     npts, F = 32 * 600 * 4, 32 * 6 * 14960 * 64 * 4
     assert abs(r["step_alg_GBps"] * r["ms_per_step"] * 1e6 - (npts * (4380 + 8504) + F)) <= 1e-6 * F

@@ -63,6 +63,14 @@ def timeit(fn, iters=40):
     return ts[len(ts) // 2]
 
 
+def step(order):
+    """A whole step as the benchmark runs it: forward, sort, then the two passes in `order`."""
+    wrapper.msmv_forward(feats, loc, w)
+    stage(_lib.BWD_STAGE_BIN)
+    for bit in order:
+        stage(bit)
+
+
 for _ in range(200):
     serial()
 torch.cuda.synchronize()
@@ -71,3 +79,8 @@ print("d feat only         %7.1f us" % timeit(lambda: stage(_lib.BWD_STAGE_DFEAT
 print("gather only         %7.1f us" % timeit(lambda: stage(_lib.BWD_STAGE_GATHER)))
 print("serial              %7.1f us" % timeit(serial))
 print("two streams (%s)    %7.1f us" % (order, timeit(forked)))
+D, G = _lib.BWD_STAGE_DFEAT, _lib.BWD_STAGE_GATHER
+print("step: forward, sort, d feat, gather   %7.1f us" % timeit(lambda: step((D, G))))
+print("step: forward, sort, gather, d feat   %7.1f us" % timeit(lambda: step((G, D))))
+print("step: forward, sort, d feat, gather   %7.1f us" % timeit(lambda: step((D, G))))
+print("step: forward, sort, gather, d feat   %7.1f us" % timeit(lambda: step((G, D))))
