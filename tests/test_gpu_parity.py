@@ -306,6 +306,29 @@ def test_slabs_with_many_points_in_no_view(wr, oracle, Q, P):
         assert torch.equal(dl2.cpu(), torch.from_numpy(dloc)) and torch.equal(dw2.cpu(), torch.from_numpy(dw))
 
 
+def test_slab_larger_than_the_sort_s_workgroups_take_in_one_round(wr, oracle):
+    """A slab of more than 16 x 1024 points: the sort's workgroups (at most 16 per slab) walk their
+    share in several rounds.  Backward against the oracle, bin-ordered forward against the plain one."""
+    levels = [(16, 44), (8, 22), (4, 11), (2, 6)]
+    feats, loc, w, grad_out = random_case(4242, levels, B=2, N=6, C=64, Q=20011, P=1, oob_frac=0.1)
+    loc[1, 5::7, :, 2] = -3.0                     # some points without a valid view, spread over the rounds
+    ref_df, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
+    out, dfeats, dloc, dw = run_hip(wr, feats, loc, w, grad_out, algo="owner")
+    assert_close(out, oracle.forward(feats, loc, w), FWD_RTOL, "forward")
+    for i in range(4):
+        assert_close(dfeats[i], ref_df[i], GRAD_RTOL, f"dfeat{i}")
+    assert_close(dloc[..., :2], ref_dloc[..., :2], GRAD_RTOL, "dloc")
+    assert_close(dw, ref_dw, GRAD_RTOL, "dw")
+    f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
+    o2, ws = wr.msmv_forward_sorted(f, l, ww)
+    assert torch.equal(o2.cpu(), torch.from_numpy(out))
+    # every slot of the sort holds a different point of its slab
+    lib = __import__("opus_amd._lib", fromlist=["x"]).load()
+    need = lib.opus_msmv_backward_workspace_bytes(4, 2, 64, 6, 20011, 1, 2)
+    ids = ws[need - 2 * 20011 * 32:].view(torch.int32).view(2 * 20011, 8)[:, 0].cpu().numpy()
+    assert sorted(ids[:20011]) == list(range(20011)) and sorted(ids[20011:]) == list(range(20011, 2 * 20011))
+
+
 # ---------------------------------------------------------------- API behaviour
 def test_autograd_functions_and_dispatch(wr, oracle):
     feats, loc, w, grad_out = random_case(21, REAL_LEVELS, B=2, N=6, C=64, Q=10, P=2)
