@@ -99,6 +99,10 @@ def parse_args(argv=None):
                          "before the W warm-up steps (a 2 ms warm-up alone leaves the first ~25 steps 10 %% slow)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 ('nccl' is RCCL on ROCm)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal of the real multi-rank path on a box with fewer GPUs than ranks: rank r computes "
+                         "on device r mod (devices visible); gloo only (RCCL refuses two ranks on one device); the "
+                         "line is marked config.shared_device and is no scaling measurement")
     ap.add_argument("--stub-compute", action="store_true",
                     help="rehearsal of the multi-rank control flow on a host without GPUs: the step is a sleep "
                          "(rank r: 2 ms x (1 + r)), nothing native is loaded; the line is marked data = 'stub'")
@@ -441,7 +445,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher: start the ranks here.  Nothing in this process has touched a GPU (importing
         # torch and counting devices does not), and the ranks are new processes, not a re-exec.
-        if not args.stub_compute and torch.cuda.device_count() < args.gpus:
+        if not args.stub_compute and not args.share_device and torch.cuda.device_count() < args.gpus:
             sys.exit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
         sys.exit(odist.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank, world, local_rank = odist.env_rank()
@@ -455,6 +459,9 @@ def main():
         load_product()
         assert torch.cuda.is_available(), "bench.py needs a HIP device"
         assert wrapper.MSMV_CUDA, "libopus_msmv.so is not loaded"
+        if args.share_device:
+            assert args.backend == "gloo", "--share-device: use --backend gloo"
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         # "nccl" is RCCL on ROCm; None when single-process
@@ -653,6 +660,7 @@ def main():
                                    f"({args.settle_ms:g} ms) to touch the buffers and leave the idle power state",
                        "frac_points_outside_image": outside,
                        "backend": None if dist is None else ("gloo" if stub else args.backend),
+                       "shared_device": bool(args.share_device),
                        "ranks": ranks,
                        "parallelism": (f"slab-parallel over {world} GPUs (one sample split, no data-path collective)"
                                        if args.split_sample else

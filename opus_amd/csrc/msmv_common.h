@@ -186,7 +186,11 @@ __device__ __forceinline__ float msmv_wave_sum(float v)
 // batch slab's feature maps are served by one XCD's L2.  Bijective for every nblk.
 __device__ __forceinline__ int msmv_xcd_remap(int bid, int nblk)
 {
+#ifdef MSMV_XCD_SHIFT
+    const int xcd = (bid + MSMV_XCD_SHIFT) & 7, within = bid >> 3;     // development aid: XCD x works on another XCD's range
+#else
     const int xcd = bid & 7, within = bid >> 3;
+#endif
     const int q = nblk >> 3, r = nblk & 7;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + within;

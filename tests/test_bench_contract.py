@@ -112,3 +112,20 @@ def test_build_then_smoke_in_one_process():
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "smoke ok" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["T-fwdbwd", "train-M"])
+def test_two_real_ranks_on_one_device(workload):
+    """The multi-rank path with real kernels: two ranks started by bench.py itself, both on this
+    box's one GPU, gloo for the rendezvous, barriers, the slowest rank's time and (train-M) the
+    bucketed all-reduce of device tensors.  Everything but RCCL itself."""
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3", "--warmup", "1",
+                  "--settle-ms", "20", "--workload", workload, "--no-cpu-baseline")
+    assert r["n_gpus"] == 2 and r["config"]["shared_device"] is True and r["config"]["backend"] == "gloo"
+    ranks = r["config"]["ranks"]
+    assert [x["rank"] for x in ranks] == [0, 1] and ranks[0]["seed"] != ranks[1]["seed"]
+    assert ranks[0]["slabs"] == [0, 32] and ranks[1]["slabs"] == [32, 64]
+    per_rank = r["config"]["points_per_step_per_gpu"]
+    assert abs(r["value"] - 2 * per_rank / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+    assert "cpu_baseline" not in r
