@@ -137,8 +137,8 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
  * opus_msmv_backward for callers that cannot allocate device memory and have no workspace to
  * hand in (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
  * It has no counterpart in the reference.  Same arguments, results and flags as
- * opus_msmv_backward without `workspace` / `workspace_bytes`: the sort's scratch (bin counters,
- * offsets and the sorted point entries, opus_msmv_backward_workspace_bytes() bytes) lives in a
+ * opus_msmv_backward without `workspace` / `workspace_bytes`: the sort's scratch (histogram
+ * table, offsets and the sorted point entries, opus_msmv_backward_workspace_bytes() bytes) lives in a
  * static device array of OPUS_MSMV_NOALLOC_SCRATCH_BYTES inside the library, one copy per GPU,
  * held until the process ends.  Sizes that need more return OPUS_MSMV_ESCRATCH (32 MiB covers
  * B*Q*P <= about 0.85 M points at N = 6, e.g. two OPUS-L samples); nothing is launched then.

@@ -329,8 +329,8 @@ int opus_msmv_backward_noalloc(int L, const float *grad_out, const float *const 
     const int rc = scratch_of_current_device(&ptr);
     if (rc != OPUS_MSMV_OK)
         return rc;
-    // the sort clears the counters it needs itself (hipMemsetAsync on `stream`) and overwrites
-    // offsets and entries: whatever an earlier call left in the array is never read
+    // nothing in the array needs clearing: the sort writes every word (histogram table, offsets,
+    // entries) that a later stage reads, so whatever an earlier call left there is never read
     return backward_impl(L, grad_out, feats, hw, loc, weights, B, 0, 0, C, N, Q, P, dfeats, dloc, dweights,
                          ptr, OPUS_MSMV_NOALLOC_SCRATCH_BYTES, flags, stream);
 }
