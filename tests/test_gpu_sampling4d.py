@@ -736,3 +736,53 @@ def test_bin_ordered_forward_full_size(ops):
     ww = torch.softmax(torch.randn((B, Q, P, 4), generator=gen, device="cuda"), -1)
     out, _ = wr.msmv_forward_sorted(f, l, ww, rows=(T, G))
     assert torch.equal(out, wr.msmv_forward(f, l, ww, rows=(T, G)))
+
+
+def test_bin_ordered_forward_and_backward_on_its_sort_replay_from_a_hip_graph(ops):
+    """The bin-ordered forward, its re-run on the kept sort and the backward on that sort allocate
+    nothing inside the library: captured once with caller-owned buffers (the wrapper's output
+    allocation aside, which the graph's pool serves), replayed on new data."""
+    from opus_amd import _lib
+    from opus_amd.csrc import wrapper as wr
+    Bs, T, G, Q, P, N, C = 1, 2, 2, 150, 2, 6, 64
+    B = Bs * T * G
+    feats, loc, w, _ = random_case(31, REAL_LEVELS, B, N, C, Q, P, 0.25)
+    f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
+    g = dev(np.random.default_rng(1).standard_normal((Bs, Q, G, T * P, C)).astype(np.float32))
+    need = wr.backward_workspace_bytes(f, l, ww, _lib.BWD_OWNER)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    out = torch.empty((Bs, Q, G, T * P, C), device="cuda")
+    out2 = torch.empty_like(out)
+    dfeats = [torch.empty_like(x) for x in f]
+    dloc, dw_ = torch.empty_like(l), torch.empty_like(ww)
+
+    def step():
+        out.copy_(wr.msmv_forward_sorted(f, l, ww, rows=(T, G), workspace=ws)[0])
+        out2.copy_(wr.msmv_forward_sorted(f, l, ww, rows=(T, G), workspace=ws, presorted=True)[0])
+        wr.msmv_backward_into(g, f, l, ww, dfeats, dloc, dw_, workspace=ws,
+                              flags=_lib.BWD_OWNER | _lib.BWD_PRESORTED, rows=(T, G))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    feats2, loc2, w2, _ = random_case(32, REAL_LEVELS, B, N, C, Q, P, 0.25)
+    for dst, src in zip(f, feats2):
+        dst.copy_(dev(src))
+    l.copy_(dev(loc2)); ww.copy_(dev(w2))
+    g.copy_(dev(np.random.default_rng(2).standard_normal(tuple(g.shape)).astype(np.float32)))
+    for t in dfeats + [dloc, dw_, out, out2]:
+        t.fill_(float("nan"))
+    ws.fill_(0xFF)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = wr.msmv_forward(f, l, ww, rows=(T, G))
+    assert torch.equal(out, want) and torch.equal(out2, want)
+    df_ref, dl_ref, dw_ref = wr.msmv_backward(g, f, l, ww, algo="owner", rows=(T, G))
+    assert torch.equal(dloc, dl_ref) and torch.equal(dw_, dw_ref)
+    for i, (a, b) in enumerate(zip(dfeats, df_ref)):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-5, f"replayed dfeat{i}")
