@@ -100,6 +100,38 @@ __global__ void __launch_bounds__(256) fill_rows_of_wg(float *dst)
     }
 }
 
+// the two patch shapes again, but every wave first waits a pseudo-random 0 .. `spread` cycles (the waves
+// of the real kernel reach their stores at different times) and holds `lds` bytes of LDS per workgroup
+template <int PH, int PW, bool NT, bool BARRIER = false>
+__global__ void __launch_bounds__(256) fill_patch_delayed(float *dst, int spread)
+{
+    const int lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    constexpr int PCOLS = W / PW, PROWS = H / PH, PATCHES = PCOLS * PROWS;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3, q = gridDim.x >> 3;
+    const int id = xcd * q + within;
+    const int slab = id / (PATCHES / 4);
+    const int patch = (id % (PATCHES / 4)) * 4 + wave;
+    const int prow = patch / PCOLS, pcol = patch % PCOLS;
+    float *base = dst + ((size_t)slab * H * W + (size_t)prow * PH * W + pcol * PW) * 64;
+    const unsigned h = ((unsigned)(bid * 4 + wave) * 2654435761u) >> 16;
+    const long long wait = spread ? (long long)(h % (unsigned)spread) : 0;
+    const long long t0 = clock64();
+    while (clock64() - t0 < wait) {}
+    if (BARRIER)
+        __syncthreads();                       // the workgroup's four waves store together
+    const float v = (float)lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2);
+        const int pr = i / PW, pc = i % PW + 4 * half;
+        float *o = base + ((size_t)pr * W + pc) * 64 + l32;
+        st<NT>(o, v);
+        st<NT>(o + 32, v);
+    }
+}
+
 template <typename F> float time_it(F f, int reps = 20)
 {
     hipEvent_t a, b;
@@ -119,7 +151,7 @@ int main()
     const size_t bytes = (size_t)SLABS * H * W * 256;
     float *d; hipMalloc(&d, bytes);
     const size_t n4 = bytes / 16;
-    auto rep = [&](const char *name, float us) { printf("%-42s %8.1f us  %6.2f TB/s\n", name, us, bytes / us / 1e6); };
+    auto rep = [&](const char *name, float us) { printf("%-56s %8.1f us  %6.2f TB/s\n", name, us, bytes / us / 1e6); };
     rep("sequential plain", time_it([&] { fill_seq<false><<<(unsigned)((n4 + 255) / 256), 256>>>(d, n4); }));
     rep("sequential nt", time_it([&] { fill_seq<true><<<(unsigned)((n4 + 255) / 256), 256>>>(d, n4); }));
 #define PATCH(PH, PW)                                                                                  \
@@ -139,6 +171,17 @@ int main()
     rep("patch 4x8 nt + 21.5 KiB LDS/WG", time_it([&] { fill_patch<4, 8, true><<<SLABS * (H / 4) * (W / 8) / 4, 256, 21504>>>(d); }));
     rep("patch 4x8 nt + 40 KiB LDS/WG", time_it([&] { fill_patch<4, 8, true><<<SLABS * (H / 4) * (W / 8) / 4, 256, 40960>>>(d); }));
     rep("patch 1x32 nt + 21.5 KiB LDS/WG", time_it([&] { fill_patch<1, 32, true><<<SLABS * (H / 1) * (W / 32) / 4, 256, 21504>>>(d); }));
+    for (int spread : {0, 2000, 8000}) {
+        char name[96];
+        snprintf(name, sizeof name, "patch 4x8 nt, waves delayed 0..%d cycles", spread);
+        rep(name, time_it([&] { fill_patch_delayed<4, 8, true><<<SLABS * (H / 4) * (W / 8) / 4, 256>>>(d, spread); }));
+        snprintf(name, sizeof name, "patch 1x32 nt, waves delayed 0..%d cycles", spread);
+        rep(name, time_it([&] { fill_patch_delayed<1, 32, true><<<SLABS * (H / 1) * (W / 32) / 4, 256>>>(d, spread); }));
+        snprintf(name, sizeof name, "patch 4x8 nt, delayed 0..%d, barrier before stores", spread);
+        rep(name, time_it([&] { fill_patch_delayed<4, 8, true, true><<<SLABS * (H / 4) * (W / 8) / 4, 256>>>(d, spread); }));
+        snprintf(name, sizeof name, "patch 1x32 nt, delayed 0..%d, barrier before stores", spread);
+        rep(name, time_it([&] { fill_patch_delayed<1, 32, true, true><<<SLABS * (H / 1) * (W / 32) / 4, 256>>>(d, spread); }));
+    }
     hipError_t e = hipDeviceSynchronize();
     printf("%s\n", hipGetErrorString(e));
     return 0;
