@@ -101,8 +101,9 @@ def parse_args(argv=None):
                     help="process-group backend for N > 1 ('nccl' is RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal of the real multi-rank path on a box with fewer GPUs than ranks: rank r computes "
-                         "on device r mod (devices visible); gloo only (RCCL refuses two ranks on one device); the "
-                         "line is marked config.shared_device and is no scaling measurement")
+                         "on device r mod (devices visible); gloo only (RCCL refuses two ranks on one device), "
+                         "workloads without the gradient all-reduce; the line is marked config.shared_device "
+                         "and is no scaling measurement")
     ap.add_argument("--stub-compute", action="store_true",
                     help="rehearsal of the multi-rank control flow on a host without GPUs: the step is a sleep "
                          "(rank r: 2 ms x (1 + r)), nothing native is loaded; the line is marked data = 'stub'")
@@ -406,6 +407,10 @@ def cpu_baseline(variant, do_bwd, slabs=8, reps=5):
                       f"formulation (oracle/torch_ref.py), median of {reps} runs after 1 warm-up"}
 
 
+def wl_has_allreduce(workload):
+    return workload == "train-M"
+
+
 def traffic_key(workload, batch, points):
     return f"{workload}|batch={batch}|points={points}"
 
@@ -461,6 +466,7 @@ def main():
         assert wrapper.MSMV_CUDA, "libopus_msmv.so is not loaded"
         if args.share_device:
             assert args.backend == "gloo", "--share-device: use --backend gloo"
+            assert not wl_has_allreduce(args.workload), "--share-device: workloads without the gradient all-reduce"
             local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
@@ -567,7 +573,9 @@ def main():
         else:
             one_step(i % args.event_every == 0)
     odist.fence(dist, device)
-    elapsed = odist.max_over_ranks(time.perf_counter() - t0, dist, device)
+    # (gloo reduces host tensors; handing it device tensors of a GPU two ranks share can hang)
+    elapsed = odist.max_over_ranks(time.perf_counter() - t0, dist,
+                                   device if args.backend == "nccl" and not stub else torch.device("cpu"))
     if graph is not None:
         for _ in range(min(args.steps, 10)):
             one_step(True)

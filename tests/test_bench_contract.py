@@ -115,13 +115,13 @@ def test_build_then_smoke_in_one_process():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["T-fwdbwd", "train-M"])
-def test_two_real_ranks_on_one_device(workload):
+def test_two_real_ranks_on_one_device():
     """The multi-rank path with real kernels: two ranks started by bench.py itself, both on this
-    box's one GPU, gloo for the rendezvous, barriers, the slowest rank's time and (train-M) the
-    bucketed all-reduce of device tensors.  Everything but RCCL itself."""
+    box's one GPU, gloo (host tensors only) for the rendezvous, barriers and the slowest rank's time.
+    (The gradient all-reduce of train-M is rehearsed under gloo with the compute stubbed, on CPUs:
+    gloo reducing device tensors of a GPU that two ranks share hung once in three runs.)"""
     r = run_bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3", "--warmup", "1",
-                  "--settle-ms", "20", "--workload", workload, "--no-cpu-baseline")
+                  "--settle-ms", "20", "--workload", "T-fwdbwd", "--no-cpu-baseline", timeout=100)
     assert r["n_gpus"] == 2 and r["config"]["shared_device"] is True and r["config"]["backend"] == "gloo"
     ranks = r["config"]["ranks"]
     assert [x["rank"] for x in ranks] == [0, 1] and ranks[0]["seed"] != ranks[1]["seed"]
