@@ -132,6 +132,48 @@ __global__ void __launch_bounds__(256) fill_patch_delayed(float *dst, int spread
     }
 }
 
+// cache-policy sweep on the 4 x 8 patch with desynchronised waves: the policy bits of the vector store
+template <int POL> __device__ __forceinline__ void st_pol(float *p, float v)
+{
+    if (POL == 0) asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (POL == 1) asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 2) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (POL == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (POL == 4) asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 5) asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 6) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if (POL == 7) asm volatile("global_store_dword %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int POL>
+__global__ void __launch_bounds__(256) fill_patch_pol(float *dst, int spread)
+{
+    constexpr int PH = 4, PW = 8;
+    const int lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    constexpr int PCOLS = W / PW, PROWS = H / PH, PATCHES = PCOLS * PROWS;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3, q = gridDim.x >> 3;
+    const int id = xcd * q + within;
+    const int slab = id / (PATCHES / 4);
+    const int patch = (id % (PATCHES / 4)) * 4 + wave;
+    const int prow = patch / PCOLS, pcol = patch % PCOLS;
+    float *base = dst + ((size_t)slab * H * W + (size_t)prow * PH * W + pcol * PW) * 64;
+    const unsigned h = ((unsigned)(bid * 4 + wave) * 2654435761u) >> 16;
+    const long long wait = spread ? (long long)(h % (unsigned)spread) : 0;
+    const long long t0 = clock64();
+    while (clock64() - t0 < wait) {}
+    const float v = (float)lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2);
+        const int pr = i / PW, pc = i % PW + 4 * half;
+        float *o = base + ((size_t)pr * W + pc) * 64 + l32;
+        st_pol<POL>(o, v);
+        st_pol<POL>(o + 32, v);
+    }
+}
+
 template <typename F> float time_it(F f, int reps = 20)
 {
     hipEvent_t a, b;
@@ -181,6 +223,12 @@ int main()
         rep(name, time_it([&] { fill_patch_delayed<4, 8, true, true><<<SLABS * (H / 4) * (W / 8) / 4, 256>>>(d, spread); }));
         snprintf(name, sizeof name, "patch 1x32 nt, delayed 0..%d, barrier before stores", spread);
         rep(name, time_it([&] { fill_patch_delayed<1, 32, true, true><<<SLABS * (H / 1) * (W / 32) / 4, 256>>>(d, spread); }));
+    }
+    {
+        const unsigned grid = SLABS * (H / 4) * (W / 8) / 4;
+#define POL(N, NAME) rep("patch 4x8 delayed 0..2000, policy " NAME, time_it([&] { fill_patch_pol<N><<<grid, 256>>>(d, 2000); }));
+        POL(0, "(none)") POL(1, "nt") POL(2, "sc1") POL(3, "sc0 sc1") POL(4, "sc1 nt") POL(5, "sc0 sc1 nt") POL(6, "sc0") POL(7, "sc0 nt")
+        POL(0, "(none)") POL(1, "nt")
     }
     hipError_t e = hipDeviceSynchronize();
     printf("%s\n", hipGetErrorString(e));
