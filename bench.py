@@ -97,6 +97,9 @@ def parse_args(argv=None):
                     help="set-up, outside warm-up and timed region: run the step back to back for this long "
                          "so that every buffer has been touched and the device has left its idle power state "
                          "before the W warm-up steps (a 2 ms warm-up alone leaves the first ~25 steps 10 %% slow)")
+    ap.add_argument("--init-group", action="store_true",
+                    help="with one rank: initialise the process group all the same, so that barriers, the "
+                         "timing reduction and train-M's all-reduce go through the backend (a group of one)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 ('nccl' is RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",
@@ -471,7 +474,7 @@ def main():
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         # "nccl" is RCCL on ROCm; None when single-process
-        dist = odist.init(args.backend, device if args.backend == "nccl" else None)
+        dist = odist.init(args.backend, device if args.backend == "nccl" else None, force=args.init_group)
 
     # ---- workload
     wl = args.workload
@@ -669,6 +672,7 @@ def main():
                        "frac_points_outside_image": outside,
                        "backend": None if dist is None else ("gloo" if stub else args.backend),
                        "shared_device": bool(args.share_device),
+                       "allreduce_bytes_per_step": sum(b.numel() * 4 for b in grad_buckets),
                        "ranks": ranks,
                        "parallelism": (f"slab-parallel over {world} GPUs (one sample split, no data-path collective)"
                                        if args.split_sample else

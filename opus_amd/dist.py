@@ -23,13 +23,19 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend, device=None):
-    """Initialise the default process group if WORLD_SIZE > 1; returns torch.distributed or None."""
-    _, world, _ = env_rank()
-    if world == 1:
+def init(backend, device=None, force=False):
+    """Initialise the default process group if WORLD_SIZE > 1; returns torch.distributed or None.
+    ``force``: also with one rank (a group of one: every collective then goes through the backend's
+    library and returns its input - a rehearsal of the calls, e.g. of RCCL on a one-GPU machine)."""
+    rank, world, _ = env_rank()
+    if world == 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", "1")
     if not dist.is_initialized():
         kwargs = {}
         if device is not None and backend == "nccl":

@@ -98,6 +98,18 @@ def test_training_step_workload_runs_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_rccl_calls_of_the_multi_rank_path_in_a_group_of_one():
+    """The calls the N > 1 path makes - process-group initialisation bound to the device, barriers,
+    the MAX reduction of the elapsed time, train-M's bucketed all-reduce on a side stream - through
+    RCCL itself, in a group of one rank (this box has one GPU; RCCL refuses two ranks on one device)."""
+    r = run_bench("--gpus", "1", "--init-group", "--workload", "train-M", "--steps", "2", "--warmup", "1",
+                  "--settle-ms", "20", "--no-cpu-baseline", timeout=200)
+    assert r["n_gpus"] == 1 and r["config"]["backend"] == "nccl"
+    assert r["config"]["allreduce_bytes_per_step"] == 300 * 1000 * 1000
+    assert r["value"] > 0
+
+
+@pytest.mark.gpu
 def test_self_launch_with_one_gpu_is_the_plain_run():
     r = run_bench("--gpus", "1", "--workload", "T-fwd", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert r["n_gpus"] == 1 and r["config"]["backend"] is None
