@@ -20,6 +20,8 @@
 //              accumulates the contributions in fp32 MFMA registers and stores the patch
 //              once (zeros included).  d loc / d w come from a separate gather kernel shaped
 //              like the forward (row of 16 lanes per point).  C == 64, L in {4, 5}.
+#include <type_traits>
+#include <utility>
 #include "msmv_common.h"
 #include "msmv_launch.h"
 
@@ -537,7 +539,7 @@ typedef __attribute__((address_space(3))) void *msmv_lptr_t;
 #define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave: with the queue, LDS never limits the occupancy
 #endif
 #ifndef MSMV_OWN_OCC
-#define MSMV_OWN_OCC 4, 8
+#define MSMV_OWN_OCC (MULTI || ACC ? 4 : 7), 8  // the plain single-set kernel fits 7 waves per SIMD (72 VGPRs)
 #endif
 
 // d feat is written once and not read again by this pass: a streaming (non-temporal) store
@@ -558,6 +560,38 @@ __device__ __forceinline__ float msmv_load_stream(const float *p)
 #else
     return *p;
 #endif
+}
+
+// global -> LDS copy of 16 bytes per lane (lane i's land at dst + 16 i) without a register
+// destination, as an opaque instruction: the compiler's wait-count pass, which knows nothing of the
+// copies in flight, then leaves the waiting to the counted waits written here (it would put a full
+// wait in front of every LDS read that follows such a copy in straight-line code).
+// (M0 carries the LDS address of such a copy; the compiler, which warns about it being named as
+// clobbered, keeps nothing in it in these kernels.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void msmv_load_to_lds_b128(const float *src, const float4 *dst)
+{
+    const unsigned lds = (unsigned)(uintptr_t)(msmv_lptr_t)dst;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+template <int N> __device__ __forceinline__ void msmv_wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int... I, class F>
+__device__ __forceinline__ void msmv_static_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant
+template <int N, class F> __device__ __forceinline__ void msmv_static_for(F &&f)
+{
+    msmv_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 // Inclusive prefix sum over the first LANES lanes of a wave (LANES = 8: within one DPP row;
@@ -919,51 +953,62 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
                                 go = gout_tab[__float_as_int(queue[rec * REC_DW + 1])];
                             const int row = PT == 4 ? rpt >> 2 : PT == 2 ? rpt >> 1 : rpt;
                             const float *src = go + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
-                            __builtin_amdgcn_global_load_lds((msmv_gptr_t)src,
-                                                             (msmv_lptr_t)(stage + (v % NS) * UNIT_F4 + j * 64), 16, 0, 0);
+                            msmv_load_to_lds_b128(src, stage + (v % NS) * UNIT_F4 + j * 64);
                         }
                     };
+                    // what the applying lane needs of unit v's records: its weight per pair and, for
+                    // P > 1, where in the staged row its point's channels sit
+                    auto load_q = [&](int v, float (&wa)[PPU], int (&po)[PPU]) {
 #pragma unroll
-                    for (int v = 0; v < D; ++v)
-                        if (v < nunits)                                // wave-uniform
-                            issue(v);
-#pragma unroll
-                    for (int v = 0; v < NU; ++v) {
-                        if (v < nunits) {                              // wave-uniform
-                            if (v + D < NU && v + D < nunits)
-                                issue(v + D);
-                            // loads issued after unit v's: those of min(D, nunits - 1 - v) units
-                            const int ahead = min(D, nunits - 1 - v) * IPU;
-                            if (ahead >= 3)
-                                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                            else if (ahead == 2)
-                                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                            else if (ahead == 1)
-                                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                            else
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            const float *sp0 = reinterpret_cast<const float *>(stage + (v % NS) * UNIT_F4 + half * ROW_F4) +
-                                               l32 * (PT == 1 ? 1 : PT);
-#pragma unroll
-                            for (int k2 = 0; k2 < PPU; ++k2) {
-                                const int u = v * PPU + k2;            // pair: records 2u and 2u + 1
-                                const float wa = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
-                                const float *sp = sp0 + k2 * 2 * ROW_F4 * 4;
-                                float g0, g1;
-                                if constexpr (PT == 1) {
-                                    g0 = sp[0];
-                                    g1 = sp[32];
-                                } else {
-                                    const int p = __float_as_int(q_pt[u * 2 * REC_DW]) & (PT - 1);
-                                    g0 = sp[p];
-                                    g1 = sp[32 * PT + p];
-                                }
-                                MSMV_OWN_MFMA(wa, g0, g1)
-                                if constexpr (ACC)
-                                    touched = touched || wa != 0.f;
-                            }
+                        for (int k2 = 0; k2 < PPU; ++k2) {
+                            const int u = v * PPU + k2;                // pair: records 2u and 2u + 1
+                            wa[k2] = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
+                            po[k2] = PT == 1 ? 0 : __float_as_int(q_pt[u * 2 * REC_DW]) & (PT - 1);
                         }
-                    }
+                    };
+                    auto apply = [&](int v, const float (&wa)[PPU], const int (&po)[PPU]) {
+                        const float *sp0 = reinterpret_cast<const float *>(stage + (v % NS) * UNIT_F4 + half * ROW_F4) +
+                                           l32 * (PT == 1 ? 1 : PT);
+#pragma unroll
+                        for (int k2 = 0; k2 < PPU; ++k2) {
+                            const float *sp = sp0 + k2 * 2 * ROW_F4 * 4;
+                            const float g0 = sp[po[k2]], g1 = sp[32 * (PT == 1 ? 1 : PT) + po[k2]];
+                            MSMV_OWN_MFMA(wa[k2], g0, g1)
+                            if constexpr (ACC)
+                                touched = touched || wa[k2] != 0.f;
+                        }
+                    };
+                    // A round of NUV units as straight-line code (every bound a constant: no branch
+                    // keeps the compiler from moving loads up): the queue values of unit v + 1 are
+                    // fetched and the rows of unit v + D requested before unit v's rows are waited for.
+                    auto run_round = [&](auto nuv_c) {
+                        constexpr int NUV = decltype(nuv_c)::value;
+                        // (a unit of one pair fetches its queue values one unit ahead; units of
+                        // several pairs overlap within themselves and keep the registers)
+                        constexpr bool AHEAD = PPU == 1;
+                        float wa[2][PPU];
+                        int po[2][PPU];
+                        if constexpr (AHEAD)
+                            load_q(0, wa[0], po[0]);
+                        msmv_static_for<(D < NUV ? D : NUV)>([&](auto vc) { issue(decltype(vc)::value); });
+                        msmv_static_for<NUV>([&](auto vc) {
+                            constexpr int v = decltype(vc)::value;
+                            if constexpr (v + D < NUV)
+                                issue(v + D);
+                            if constexpr (AHEAD && v + 1 < NUV)
+                                load_q(v + 1, wa[(v + 1) & 1], po[(v + 1) & 1]);
+                            if constexpr (!AHEAD)
+                                load_q(v, wa[v & 1], po[v & 1]);
+                            // loads issued after unit v's: those of min(D, NUV - 1 - v) units
+                            msmv_wait_vmcnt<(D < NUV - 1 - v ? D : NUV - 1 - v) * IPU>();
+                            apply(v, wa[v & 1], po[v & 1]);
+                        });
+                    };
+                    msmv_static_for<NU>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value + 1;
+                        if (nunits == k)                               // wave-uniform
+                            run_round(std::integral_constant<int, k>{});
+                    });
                     // the next round's copies and queue writes must not overtake this round's LDS reads
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else {
