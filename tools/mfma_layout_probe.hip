@@ -17,20 +17,16 @@ int main()
     hipMalloc(&d, sizeof h);
     k<<<1, 64>>>(d);
     hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
-    // D[l][v] = A[la] * B[lb]: recover la, lb
+    // expectation: D[lane l][v] = A[lane 4 * (l / 4) + v] * B[lane l]
     int ok = 1;
     for (int l = 0; l < 64; ++l)
         for (int v = 0; v < 4; ++v) {
             const long long p = (long long)(h[l * 4 + v] + 0.5f);
-            const int lb = (int)(p / 1000 / 1) ;      // p = (la+1) * 1000 * (lb+1)
-            int la = -1, lbb = -1;
-            for (int a = 1; a <= 64 && la < 0; ++a)
-                if (p % (1000LL * a) == 0 && p / (1000LL * a) >= 1 && p / (1000LL * a) <= 64) {
-                    // ambiguous factorisations exist; prefer the expected one
-                }
-            const int ea = (l / 4) * 4 + v + 1, eb = l + 1;   // expectation: A from lane 4*(l/4)+v, B from lane l
-            if (p != 1000LL * ea * eb) { ok = 0; printf("lane %d v %d: got %lld, expected %lld\n", l, v, p, 1000LL * ea * eb); }
-            (void)lb; (void)lbb;
+            const int ea = (l / 4) * 4 + v + 1, eb = l + 1;
+            if (p != 1000LL * ea * eb) {
+                ok = 0;
+                printf("lane %d v %d: got %lld, expected %lld\n", l, v, p, 1000LL * ea * eb);
+            }
         }
     printf(ok ? "layout as expected: D[lane l][v] = A[lane 4*(l/4)+v] * B[lane l]\n" : "layout differs\n");
     return 0;
