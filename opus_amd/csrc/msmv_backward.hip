@@ -462,8 +462,8 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
 // of hits where four compare / select pairs used to pick the corner that lands on the pixel.
 // Corners outside the image need no test: their rows / columns belong to no stored pixel.
 //
-// A wave applies its hits one after the other and keeps only two groups of gradient loads in
-// flight, so its run time grows with the hits of its patch: a patch of a coarse level (or of a
+// A wave applies its hits one after the other with a few units of gradient rows in flight (a
+// queue round is straight-line code, see the kernel), so its run time grows with the hits of its patch: a patch of a coarse level (or of a
 // crowded image region) collects hundreds of hits where a fine one collects a handful, and
 // those few long waves would finish last.  A level whose patches expect many hits is
 // therefore worked on by K = 2 or 4 waves per patch: wave k of the K takes entries
