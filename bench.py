@@ -88,10 +88,14 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph and time its replays (no launch gaps); the "
                          "per-kernel durations then come from evented steps run after the timed region")
-    ap.add_argument("--event-every", type=int, default=4,
-                    help="record the per-kernel HIP events in every n-th timed step only: an event record "
-                         "idles the GPU for several microseconds, five of them per step cost ~8 %% of an "
-                         "OPUS-L step (1 = every step)")
+    ap.add_argument("--event-steps", type=int, default=24,
+                    help="steps run AFTER the timed region with a HIP event between all launches: the per-kernel "
+                         "durations (and the roofline, from their median) rest on this many launches whatever "
+                         "--steps is")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="additionally record the per-kernel events in every n-th step of the timed region "
+                         "(0 = never: an event record idles the GPU for several microseconds, five of them per "
+                         "step cost ~8 %% of an OPUS-L step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="set-up, outside warm-up and timed region: run the step back to back for this long "
@@ -107,6 +111,10 @@ def parse_args(argv=None):
                          "on device r mod (devices visible); gloo only (RCCL refuses two ranks on one device), "
                          "workloads without the gradient all-reduce; the line is marked config.shared_device "
                          "and is no scaling measurement")
+    ap.add_argument("--rank-timeout", type=float, default=None,
+                    help="self-launched ranks (no launcher, --gpus > 1): seconds after which ranks still running "
+                         "are terminated, then killed, and the exit status is 124 (default: OPUS_RANK_TIMEOUT_S "
+                         "or 600)")
     ap.add_argument("--stub-compute", action="store_true",
                     help="rehearsal of the multi-rank control flow on a host without GPUs: the step is a sleep "
                          "(rank r: 2 ms x (1 + r)), nothing native is loaded; the line is marked data = 'stub'")
@@ -133,8 +141,7 @@ def camera_sets(Bp, Q, P, seed, device, n_sets, from_queries=False):
     """Caller-side inputs of sampling_4d: 3-D points in pc_range = [-40,-40,-1, 40,40,5.4]
     (configs/opus-*: point_cloud_range), softmax scale weights, ring-of-cameras occ2img."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from procedural import synthetic_occ2img
+    from tools.synthetic_cameras import synthetic_occ2img
     T, G, N, L = 8, 4, N_VIEWS, len(LEVELS)
     B = Bp // (T * G)
     gen = torch.Generator(device=device).manual_seed(seed)
@@ -296,7 +303,9 @@ class Step:
         else:
             fn()
 
-    def run(self, record=True):
+    def run(self, record=True, after_backward=None):
+        """`after_backward(layer)` is called when a layer's backward launches have been issued (the
+        training workload hands the layer's gradient buckets to the all-reduce there)."""
         self._boundary = None
         for layer, (loc, w, g) in enumerate(self.sets):
             # layers of one decoder sample the same feature maps: the first backward writes
@@ -356,6 +365,8 @@ class Step:
             if self.caller:
                 self._timed("msmv_project_pack_bwd", lambda: opus_sampling.project_pack_backward_into(
                     self.dloc, self.dw, pts, occ2img, loc, 256, 704, N_VIEWS, self.dpts, self.dsw), record)
+            if after_backward is not None:
+                after_backward(layer)
         if self.defer:
             _, Q, P, _ = self.sets[0][0].shape
             cap = _lib.load().opus_msmv_dfeat_max_sets()
@@ -427,7 +438,12 @@ def load_traffic(workload, batch, points, kernel):
     try:
         with open(path) as f:
             t = json.load(f)
-        rec = t.get(traffic_key(workload, batch, points), {}).get(kernel)
+        conf = t.get(traffic_key(workload, batch, points), {})
+        # a figure measured on other kernel sources is no figure either
+        from tools.buildinfo import csrc_hash
+        if conf.get("_csrc_sha256") != csrc_hash():
+            return None
+        rec = conf.get(kernel)
         return rec if rec is None or isinstance(rec, dict) else {"bytes": rec}
     except (OSError, ValueError):
         return None
@@ -437,15 +453,66 @@ class StubStep:
     """--stub-compute: stands in for Step so that the rank logic around it (sharding, seeds,
     fences, the slowest rank's time, rank 0's line) can be rehearsed with gloo on CPUs."""
 
-    def __init__(self, rank):
+    def __init__(self, rank, n_layers=1):
         self.rank = rank
+        self.n_layers = n_layers
         self.defer = False
 
-    def run(self, record=True):
-        time.sleep(0.002 * (1 + self.rank))
+    def run(self, record=True, after_backward=None):
+        for layer in range(self.n_layers):
+            time.sleep(0.002 * (1 + self.rank) / self.n_layers)
+            if after_backward is not None:
+                after_backward(layer)
 
     def kernel_ms(self):
-        return {"stub_sleep": (2.0 * (1 + self.rank), 1, 0.0, 0.0, 0.0)}
+        ms = 2.0 * (1 + self.rank)
+        return {"stub_sleep": (ms, 1, ms, ms, ms)}
+
+
+class GradReducer:
+    """The DDP-style gradient all-reduce of the training configuration (train.py:123 of the reference
+    wraps the model in DistributedDataParallel, which reduces a bucket as soon as the backward sweep
+    has produced its gradients): the step's buckets are dealt out over its layers, a layer's share is
+    handed to the collective when that layer's backward has been issued, and the step joins the
+    collective once, at its end.  Nothing of it is on the op's data path.
+
+    Device tensors (RCCL): every bucket is reduced on a side stream behind an event recorded on the
+    compute stream - the buckets of layer i are on the wire while layers i + 1 .. run (the last
+    layer's while the deferred d-feat pass runs); `join` makes the compute stream wait for the side
+    stream.  Host tensors (gloo): asynchronous work handles, waited for in `join`."""
+
+    def __init__(self, dist, buckets, n_layers, comm_stream=None):
+        self.dist, self.buckets, self.n_layers, self.comm_stream = dist, buckets, n_layers, comm_stream
+        self.per_layer = -(-len(buckets) // n_layers)
+        self.pending = []
+        self.log = []                 # (layer, bucket) in issue order, first step only
+        self._logging = True
+
+    def after_backward(self, layer):
+        lo = layer * self.per_layer
+        mine = range(lo, min(lo + self.per_layer, len(self.buckets)))
+        if not mine:
+            return
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                for i in mine:
+                    self.dist.all_reduce(self.buckets[i])
+        else:
+            for i in mine:
+                self.pending.append(self.dist.all_reduce(self.buckets[i], async_op=True))
+        if self._logging:
+            self.log.extend((layer, i) for i in mine)
+
+    def join(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        self._logging = False
 
 
 def main():
@@ -455,7 +522,7 @@ def main():
         # torch and counting devices does not), and the ranks are new processes, not a re-exec.
         if not args.stub_compute and not args.share_device and torch.cuda.device_count() < args.gpus:
             sys.exit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
-        sys.exit(odist.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+        sys.exit(odist.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:], timeout_s=args.rank_timeout))
     rank, world, local_rank = odist.env_rank()
     if world != args.gpus:
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
@@ -469,7 +536,6 @@ def main():
         assert wrapper.MSMV_CUDA, "libopus_msmv.so is not loaded"
         if args.share_device:
             assert args.backend == "gloo", "--share-device: use --backend gloo"
-            assert not wl_has_allreduce(args.workload), "--share-device: workloads without the gradient all-reduce"
             local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
@@ -503,7 +569,7 @@ def main():
     seed = 1234 + rank
     caller = None
     if stub:
-        step, feats, sets = StubStep(rank), [], []
+        step, feats, sets = StubStep(rank, n_layers), [], []
     else:
         feats, sets = make_inputs(Bp, Q, P, seed, device, n_sets=n_layers)
         if args.points != "uniform" or wl.startswith("sampling4d-"):
@@ -518,25 +584,22 @@ def main():
     npts_step = Bp * Q * P * n_layers                    # sampled points per step per rank
     feat_bytes = sum(f.numel() * 4 for f in feats)
 
-    grad_buckets, comm_stream = [], None
+    reducer = None
     if allreduce_bytes and dist is not None:
         bucket = 25 * 1000 * 1000 // 4
-        grad_buckets = [torch.zeros(bucket, device=device) for _ in range(allreduce_bytes // (bucket * 4))]
-        comm_stream = torch.cuda.Stream() if not stub else None
+        # RCCL reduces device tensors on a side stream; gloo is given host tensors only (its staging of
+        # device tensors from two processes that share one GPU is where a rehearsal once hung)
+        on_device = not stub and args.backend == "nccl"
+        grad_buckets = [torch.zeros(bucket, device=device if on_device else "cpu")
+                        for _ in range(allreduce_bytes // (bucket * 4))]
+        reducer = GradReducer(dist, grad_buckets, n_layers, torch.cuda.Stream() if on_device else None)
 
-    def one_step(record):
-        step.run(record)
-        if grad_buckets and comm_stream is not None:
-            # the DDP gradient all-reduce of the training config: 25 MB buckets over RCCL on a
-            # side stream (it overlaps the next step's kernels; the op itself needs no collective)
-            comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm_stream):
-                for b in grad_buckets:
-                    dist.all_reduce(b)
-            torch.cuda.current_stream().wait_stream(comm_stream)
-        elif grad_buckets:
-            for b in grad_buckets:
-                dist.all_reduce(b)
+    def one_step(record, reduce=True):
+        if reducer is not None and reduce:
+            step.run(record, after_backward=reducer.after_backward)
+            reducer.join()
+        else:
+            step.run(record)
 
     # a generational collection of the interpreter's heap (tens of ms with torch loaded) inside
     # the timed loop would stall the launches of one step and be billed to the GPU path
@@ -557,7 +620,7 @@ def main():
         one_step(False)
     graph = None
     if args.graph:
-        assert not grad_buckets and not stub, "--graph does not cover the all-reduce workload"
+        assert reducer is None and not stub, "--graph does not cover the all-reduce workload"
         # the library neither allocates nor synchronises: a step is capturable as it is
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -574,14 +637,27 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            one_step(i % args.event_every == 0)
+            one_step(args.event_every > 0 and i % args.event_every == 0)
     odist.fence(dist, device)
     # (gloo reduces host tensors; handing it device tensors of a GPU two ranks share can hang)
     elapsed = odist.max_over_ranks(time.perf_counter() - t0, dist,
                                    device if args.backend == "nccl" and not stub else torch.device("cpu"))
-    if graph is not None:
-        for _ in range(min(args.steps, 10)):
-            one_step(True)
+    # what the collective costs the step: the same steps without it, timed the same way
+    ms_no_comm = None
+    if reducer is not None:
+        n_cmp = min(args.steps, 20)
+        odist.fence(dist, device)
+        t1 = time.perf_counter()
+        for _ in range(n_cmp):
+            one_step(False, reduce=False)
+        odist.fence(dist, device)
+        ms_no_comm = odist.max_over_ranks(time.perf_counter() - t1, dist,
+                                          device if args.backend == "nccl" and not stub else torch.device("cpu")) / n_cmp * 1e3
+    # per-kernel durations: evented steps outside the timed region (the all-reduce is not part of them)
+    event_steps = 0 if stub else max(args.event_steps, 0)
+    for _ in range(event_steps):
+        step.run(True)
+    if not stub:
         torch.cuda.synchronize()
     gc.enable()
 
@@ -602,44 +678,63 @@ def main():
         exact = args.points == "uniform"       # every corner in range: the closed forms are exact
         kernels = {}
         for name, (ms, n, p10, p50, p90) in kms.items():
+            # rates from the MEDIAN launch duration (one slow launch among a few dozen moves a mean by
+            # several per cent); the mean is kept beside it
             rec = {"avg_us": ms * 1e3, "launches": n, "p10_us": p10 * 1e3, "p50_us": p50 * 1e3, "p90_us": p90 * 1e3}
             if name in ab and (exact or name.startswith("msmv_project")):
                 rec["alg_bytes"] = ab[name]
-                rec["alg_GBps"] = ab[name] / (ms * 1e-3) / 1e9
+                rec["alg_GBps"] = ab[name] / (p50 * 1e-3) / 1e9
             if name in cb:
                 rec["compulsory_bytes"] = cb[name]
-                rec["compulsory_GBps"] = cb[name] / (ms * 1e-3) / 1e9
+                rec["compulsory_GBps"] = cb[name] / (p50 * 1e-3) / 1e9
+                rec["compulsory_GBps_mean"] = cb[name] / (ms * 1e-3) / 1e9
             t = None if stub else load_traffic(wl, args.batch, args.points, name)
             if t is not None:
                 rec["traffic_bytes"] = t["bytes"]
-                rec["traffic_GBps"] = t["bytes"] / (ms * 1e-3) / 1e9
+                rec["traffic_GBps"] = t["bytes"] / (p50 * 1e-3) / 1e9
                 for k in ("template", "l2_hit_rate"):
                     if k in t:
                         rec[k] = t[k]
             kernels[name] = rec
-        dominant = max(kms, key=lambda k: kms[k][0] * kms[k][1])
-        dom = kernels[dominant]
-        roofline = {"bound": "hbm", "kernel": dominant,
-                    # compulsory bytes of the dominant kernel / its HIP-event launch time: <= peak
-                    "achieved": dom.get("compulsory_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": (dom["compulsory_GBps"] / HBM_PEAK_GBPS) if "compulsory_GBps" in dom else None,
-                    # measured L2 <-> fabric bytes per launch (PMC passes of this configuration) or null
-                    "traffic": dom.get("traffic_bytes"),
-                    "traffic_GBps": dom.get("traffic_GBps"),
-                    "traffic_frac": (dom["traffic_GBps"] / HBM_PEAK_GBPS) if "traffic_GBps" in dom else None,
-                    "compulsory_bytes_per_launch": dom.get("compulsory_bytes"),
+
+        def roofline_of(name):
+            k = kernels[name]
+            return {"bound": "hbm", "kernel": name,
+                    # compulsory bytes of the kernel / its median HIP-event launch time: <= peak
+                    "achieved": k.get("compulsory_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": (k["compulsory_GBps"] / HBM_PEAK_GBPS) if "compulsory_GBps" in k else None,
+                    "frac_from_mean": (k["compulsory_GBps_mean"] / HBM_PEAK_GBPS) if "compulsory_GBps_mean" in k else None,
+                    # measured L2 <-> fabric bytes per launch (PMC passes of this configuration on this
+                    # build of the kernels) or null
+                    "traffic": k.get("traffic_bytes"),
+                    "traffic_GBps": k.get("traffic_GBps"),
+                    "traffic_frac": (k["traffic_GBps"] / HBM_PEAK_GBPS) if "traffic_GBps" in k else None,
+                    "compulsory_bytes_per_launch": k.get("compulsory_bytes"),
                     # the no-reuse figure of the metric's definition: above the peak where caches
                     # serve re-touched pixels
-                    "achieved_alg": dom.get("alg_GBps"), "alg_bytes_per_launch": dom.get("alg_bytes"),
-                    "frac_alg": (dom["alg_GBps"] / HBM_PEAK_GBPS) if "alg_GBps" in dom else None,
-                    "avg_launch_us": dom["avg_us"],
-                    "note": "achieved = compulsory bytes (distinct feature pixels x 256 B + the kernel's dense "
-                            "reads / writes, from the inputs) / HIP-event launch time; traffic = rocprofv3 "
-                            "FETCH_SIZE x 2 + WRITE_SIZE at the L2 -> fabric boundary (Infinity-Cache hits "
-                            "included); achieved_alg = no-reuse bytes of the metric's definition"}
+                    "achieved_alg": k.get("alg_GBps"), "alg_bytes_per_launch": k.get("alg_bytes"),
+                    "frac_alg": (k["alg_GBps"] / HBM_PEAK_GBPS) if "alg_GBps" in k else None,
+                    "avg_launch_us": k["avg_us"], "p50_launch_us": k["p50_us"], "launches": k["launches"],
+                    "share_of_kernel_time": k["p50_us"] * k["launches"] / kernel_time_total}
+
+        kernel_time_total = sum(k["p50_us"] * k["launches"] for k in kernels.values())
+        dominant = max(kernels, key=lambda k: kernels[k]["p50_us"] * kernels[k]["launches"])
+        roofline = roofline_of(dominant)
+        roofline["note"] = ("achieved = compulsory bytes (distinct feature pixels x 256 B + the kernel's dense "
+                            "reads / writes, from the inputs) / median HIP-event launch time over `launches` "
+                            "launches; traffic = rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE at the L2 -> fabric "
+                            "boundary (Infinity-Cache hits included); achieved_alg = no-reuse bytes of the "
+                            "metric's definition")
+        # the kernel furthest below the roofline among those that matter (>= 10 % of the step's kernel
+        # time: the launch-latency-sized sort and projection kernels are not bandwidth work)
+        heavy = [k for k in kernels if "compulsory_GBps" in kernels[k]
+                 and kernels[k]["p50_us"] * kernels[k]["launches"] >= 0.1 * kernel_time_total]
+        roofline_worst = roofline_of(min(heavy, key=lambda k: kernels[k]["compulsory_GBps"])) if heavy else None
         pass_bytes = (ab["forward"] * n_fwd + (ab["backward"] if do_bwd else 0)) * n_layers
         pass_compulsory = sum(kernels[k]["compulsory_bytes"] * kms[k][1] for k in kms if "compulsory_bytes" in kernels[k])
-        evented_steps = min(args.steps, 10) if graph is not None else len(range(0, args.steps, args.event_every))
+        evented_steps = event_steps + (len(range(0, args.steps, args.event_every))
+                                       if args.event_every > 0 and graph is None else 0)
+        evented_steps = max(evented_steps, 1)
         ms_per_step = elapsed / args.steps * 1e3
         outside = 0.0
         if sets:
@@ -666,18 +761,30 @@ def main():
                        "fwd_order": "bin" if getattr(step, "fwd_sorted", False) else "input",
                        "points": args.points if (not caller or args.points != "uniform") else "cameras",
                        "launch": ("HIP graph replay" if args.graph else
-                                  f"one call per kernel; HIP events between them in every {args.event_every}. timed step")
+                                  "one call per kernel, no events inside the timed region"
+                                  + (f" but in every {args.event_every}. step" if args.event_every > 0 else ""))
+                                 + f"; per-kernel durations from {event_steps} evented steps after the timed region"
                                  + f"; set-up before the warm-up: {settle_steps} untimed steps "
                                    f"({args.settle_ms:g} ms) to touch the buffers and leave the idle power state",
                        "frac_points_outside_image": outside,
                        "backend": None if dist is None else ("gloo" if stub else args.backend),
                        "shared_device": bool(args.share_device),
-                       "allreduce_bytes_per_step": sum(b.numel() * 4 for b in grad_buckets),
+                       "allreduce_bytes_per_step": sum(b.numel() * 4 for b in reducer.buckets) if reducer else 0,
+                       # (layer, bucket) in the order the buckets were handed to the collective
+                       "allreduce_schedule": reducer.log if reducer else None,
+                       "allreduce_overlap": (None if reducer is None else
+                                             "a layer's buckets are reduced on a side stream (RCCL) / by asynchronous "
+                                             "work handles (gloo, host tensors) while the following layers run; one "
+                                             "join at the end of the step"),
                        "ranks": ranks,
                        "parallelism": (f"slab-parallel over {world} GPUs (one sample split, no data-path collective)"
                                        if args.split_sample else
                                        f"dp{world} (batch-parallel, no data-path collective)")},
             "roofline": roofline,
+            "roofline_worst": roofline_worst,
+            # step time with the gradient all-reduce minus step time without it (None: no collective)
+            "allreduce_exposed_us": None if ms_no_comm is None else (ms_per_step - ms_no_comm) * 1e3,
+            "ms_per_step_without_allreduce": ms_no_comm,
             "step_alg_GBps": pass_bytes / (ms_per_step * 1e-3) / 1e9,
             "step_alg_frac_of_peak": pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             # the whole step on compulsory bytes: sum over its kernels / step time

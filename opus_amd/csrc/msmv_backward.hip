@@ -20,6 +20,7 @@
 //              accumulates the contributions in fp32 MFMA registers and stores the patch
 //              once (zeros included).  d loc / d w come from a separate gather kernel shaped
 //              like the forward (row of 16 lanes per point).  C == 64, L in {4, 5}.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include "msmv_common.h"
@@ -479,6 +480,16 @@ static_assert(PATCH_H * PATCH_W == 32, "a patch is the M = 32 dimension of the M
 // (measured 183 vs 198 us at OPUS-L; 2 waves: 175 us uniform but no better on crowded images)
 constexpr int OWN_WAVES = MSMV_OWN_WAVES;
 constexpr int OWN_THREADS = OWN_WAVES * 64;
+// Workgroup order of the d-feat pass, level-major (0) or view-major (1).  Measured at OPUS-L: one set
+// 159.5 / 165.0 us, six sets 621 / 686 us, six OPUS-M sets 353 / 404 us - view-major mixes the long
+// waves of a view's coarse levels with the store-bound ones of its neighbour's finest level, and two
+// views' rows still exceed the L2.
+#ifndef MSMV_DFEAT_VIEW_MAJOR_SINGLE
+#define MSMV_DFEAT_VIEW_MAJOR_SINGLE 0
+#endif
+#ifndef MSMV_DFEAT_VIEW_MAJOR_MULTI
+#define MSMV_DFEAT_VIEW_MAJOR_MULTI 0
+#endif
 #ifndef MSMV_OWN_SPLIT_HITS
 #define MSMV_OWN_SPLIT_HITS 64                   // expected hits per wave above which a level's patches are shared
 #endif
@@ -510,12 +521,16 @@ static_assert(sizeof(OwnerLevel) == 64, "one 64-byte scalar load per level");
 
 struct OwnerGeom {
     OwnerLevel lv[MSMV_MAX_LEVELS];
-    // workgroups of a batch slab are ordered [level, coarse first][view][tile]: seg_end[k] is the
-    // end of the k-th level in that order (level L-1-k); INT_MAX from the last level on
+    // workgroups of a batch slab are ordered [view][level, coarse first][tile] (view_major) or
+    // [level, coarse first][view][tile]: seg_end[k] is the end of the k-th level in that order
+    // (level L-1-k) within a view or within the slab; INT_MAX from the last level on
     int seg_end[MSMV_MAX_LEVELS];
     MsmvDiv div_tiles_per_b;
     int tiles_per_b;            // N * sum over levels of tiles
     int L, N, qp, P;
+    int view_major;
+    int tiles_per_view;         // sum over levels of tiles
+    MsmvDiv div_tiles_per_view;
 };
 
 // The sorted point sets one d-feat launch accumulates: normally one (this call's), several when
@@ -705,10 +720,18 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         __syncthreads();
     }
 
-    // ---- which patch: logical order [b][level, coarse first][view][tile][wave / K]
+    // ---- which patch: logical order [b][view][level, coarse first][tile][wave / K] (view_major: a
+    // view's gradient rows and bin entries are then what an XCD's L2 has to hold from one level of the
+    // view to the next - with several point sets a whole slab's no longer fit) or
+    // [b][level, coarse first][view][tile][wave / K]
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
     const int b = (int)msmv_div((uint32_t)id, geo.div_tiles_per_b);
     id -= b * geo.tiles_per_b;
+    int view_of_id = 0;
+    if (geo.view_major) {
+        view_of_id = (int)msmv_div((uint32_t)id, geo.div_tiles_per_view);
+        id -= view_of_id * geo.tiles_per_view;
+    }
     int k = 0, seg_start = 0;
 #pragma unroll
     for (int j = 0; j < MSMV_MAX_LEVELS - 1; ++j) {          // (seg_end is INT_MAX from the last level on)
@@ -725,8 +748,8 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
     id -= seg_start;
     const OwnerLevel G = geo.lv[l];
     const int N = geo.N;
-    const int view = (int)msmv_div((uint32_t)id, G.div_tiles);
-    const int tile_idx = id - view * G.tiles;
+    const int view = geo.view_major ? view_of_id : (int)msmv_div((uint32_t)id, G.div_tiles);
+    const int tile_idx = geo.view_major ? id : id - view * G.tiles;
     const int klog = G.split_log2;
     const int K = 1 << klog;                                 // waves sharing a patch
     const int sub = wave & (K - 1);                          // this wave's share: entries sub, sub + K, ...
@@ -1496,6 +1519,19 @@ static OwnerWs owner_ws_of(const MsmvArgs &a, void *workspace)
     return ws;
 }
 
+// Workgroup order of the d-feat pass: view-major or level-major (see the kernel).  OPUS_MSMV_DFEAT_ORDER
+// = "view" / "level" overrides the default for measurements.
+static int msmv_dfeat_view_major(int nsets)
+{
+    static const int forced = [] {
+        const char *e = getenv("OPUS_MSMV_DFEAT_ORDER");
+        return !e ? -1 : (e[0] == 'v' ? 1 : 0);
+    }();
+    if (forced >= 0)
+        return forced;
+    return nsets > 1 ? MSMV_DFEAT_VIEW_MAJOR_MULTI : MSMV_DFEAT_VIEW_MAJOR_SINGLE;
+}
+
 // The d-feat pass over `sets.n` sorted point sets (each of a.qp points per batch slab).
 static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hipStream_t s, bool accumulate)
 {
@@ -1524,11 +1560,14 @@ static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hi
         g.div_wm1 = msmv_make_div(g.W - 1);
         per_view += g.tiles;
     }
-    // workgroup order within a batch slab: coarse level first
+    // workgroup order within a batch slab (or within a view of it): coarse level first
+    geo.view_major = msmv_dfeat_view_major(sets.n);
+    geo.tiles_per_view = per_view;
+    geo.div_tiles_per_view = msmv_make_div(per_view);
     long long end = 0;
     for (int k = 0; k < MSMV_MAX_LEVELS; ++k) {
         if (k < a.L - 1) {
-            end += (long long)geo.lv[a.L - 1 - k].tiles * a.N;
+            end += (long long)geo.lv[a.L - 1 - k].tiles * (geo.view_major ? 1 : a.N);
             geo.seg_end[k] = (int)end;
         } else {
             geo.seg_end[k] = 0x7FFFFFFF;

@@ -86,7 +86,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(world, argv, env=None, poll_s=0.2):
+def spawn_ranks(world, argv, env=None, poll_s=0.2, timeout_s=None, grace_s=5.0):
     """Start `world` fresh interpreter processes running `argv` (script + arguments), one per
     rank, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK,
     WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port), and wait for all of them.
@@ -96,26 +96,59 @@ def spawn_ranks(world, argv, env=None, poll_s=0.2):
     interpreter), never a re-exec of this one.  Their stdout / stderr are the caller's, so the
     one line rank 0 prints is this process's output.  Returns the exit status to leave with:
     0 if every rank returned 0, else the first failing rank's status; when one rank fails, the
-    others (exactly the processes started here) are terminated instead of left waiting in a
-    collective."""
+    others (exactly the processes started here) are ended instead of left waiting in a collective.
+
+    `timeout_s` (default: OPUS_RANK_TIMEOUT_S or 600) is the deadline for the whole job: a rank that
+    is stuck - in a collective whose peer never arrives, in a driver call - would otherwise hold
+    this process for ever.  On expiry every rank still running is ended and the status is 124.
+    Ending a rank is SIGTERM, then SIGKILL after `grace_s` seconds (a process blocked inside a
+    collective or the GPU driver may not act on the first).  Whatever ends this function - return,
+    exception, KeyboardInterrupt - no child started here is left running."""
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("OPUS_RANK_TIMEOUT_S", "600"))
     base = dict(os.environ if env is None else env)
     base.update(WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     procs = []
-    for rank in range(world):
-        e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+
+    def end_all():
+        running = [p for p in procs if p.poll() is None]
+        for p in running:
+            p.terminate()
+        t_kill = time.monotonic() + grace_s
+        for p in running:
+            try:
+                p.wait(timeout=max(0.0, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for p in running:
+            p.wait()
+
     status = 0
-    live = set(range(world))
-    while live:
-        for r in sorted(live):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            live.discard(r)
-            if rc != 0 and status == 0:
-                status = rc if rc > 0 else 128 - rc
-                for o in live:
-                    procs[o].terminate()
-        if live:
-            time.sleep(poll_s)
+    try:
+        for rank in range(world):
+            e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+        deadline = time.monotonic() + timeout_s
+        live = set(range(world))
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 128 - rc
+            if status != 0 and live:
+                end_all()                    # the survivors would wait for the failed rank for ever
+                live.clear()
+            elif live and time.monotonic() > deadline:
+                print(f"spawn_ranks: rank(s) {sorted(live)} still running after {timeout_s:g} s - ending them",
+                      file=sys.stderr, flush=True)
+                end_all()
+                live.clear()
+                status = 124
+            elif live:
+                time.sleep(poll_s)
+    finally:
+        end_all()
     return status

@@ -21,14 +21,31 @@ def run_bench(*args, timeout=300):
     return json.loads(lines[0])
 
 
-def test_traffic_of_another_configuration_is_null_not_borrowed():
+def test_traffic_of_another_configuration_is_null_not_borrowed(monkeypatch):
     """A PMC figure is keyed by workload, batch and point distribution: anything else reads as None."""
     sys.path.insert(0, ROOT)
     import bench
+    from tools import buildinfo
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    # (as if the sources were still the ones the record was measured on)
+    monkeypatch.setattr(buildinfo, "csrc_hash", lambda: t["T-fwdbwd|batch=1|points=uniform"]["_csrc_sha256"])
     assert bench.load_traffic("T-fwdbwd", 1, "uniform", "msmv_bwd_owner_dfeat")["bytes"] > 0
     assert bench.load_traffic("T-fwdbwd", 8, "uniform", "msmv_bwd_owner_dfeat") is None
     assert bench.load_traffic("T-fwdbwd", 1, "cameras", "msmv_bwd_owner_dfeat") is None
     assert bench.load_traffic("T-fwdbwd", 1, "uniform", "no_such_kernel") is None
+
+
+def test_traffic_measured_on_other_kernel_sources_is_null(monkeypatch):
+    """Every record carries the hash of the kernel sources it was measured on; once they change the
+    stale figure is no longer reported."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tools import buildinfo
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    measured = [k for k, v in t.items() if isinstance(v, dict)]
+    assert measured and all("_csrc_sha256" in t[k] for k in measured)
+    monkeypatch.setattr(buildinfo, "csrc_hash", lambda: "0" * 16)
+    assert bench.load_traffic("T-fwdbwd", 1, "uniform", "msmv_bwd_owner_dfeat") is None
 
 
 def test_help_lists_the_contract_flags():
@@ -56,12 +73,23 @@ def test_result_line_carries_every_contract_field():
     assert roof["achieved"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert roof["frac"] <= 1.0 and roof["achieved_alg"] >= roof["achieved"]
     k = r["kernels"][roof["kernel"]]
-    assert abs(roof["achieved"] - k["compulsory_bytes"] / (k["avg_us"] * 1e-6) / 1e9) <= 1e-6 * roof["achieved"]
-    # traffic: the committed PMC pass of exactly this workload | batch | points (profiles/traffic.json)
+    # ... over the MEDIAN of at least 20 evented launches, whatever --steps is
+    assert k["launches"] >= 20 and roof["launches"] == k["launches"]
+    assert abs(roof["achieved"] - k["compulsory_bytes"] / (k["p50_us"] * 1e-6) / 1e9) <= 1e-6 * roof["achieved"]
+    worst = r["roofline_worst"]
+    assert worst["frac"] <= roof["frac"] + 1e-12 and worst["share_of_kernel_time"] >= 0.1
+    # traffic: the committed PMC pass of exactly this workload | batch | points (profiles/traffic.json),
+    # reported only while the kernel sources are the ones it was measured on
+    sys.path.insert(0, ROOT)
+    from tools.buildinfo import csrc_hash
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-        rec = json.load(f)["T-fwdbwd|batch=1|points=uniform"][roof["kernel"]]
-    assert roof["traffic"] == rec["bytes"] and rec["template"].startswith(roof["kernel"])
-    assert roof["traffic"] <= 1.1 * k["compulsory_bytes"], "the dominant kernel moves what it must, not more"
+        conf = json.load(f)["T-fwdbwd|batch=1|points=uniform"]
+    rec = conf[roof["kernel"]]
+    if conf["_csrc_sha256"] == csrc_hash():
+        assert roof["traffic"] == rec["bytes"] and rec["template"].startswith(roof["kernel"])
+        assert roof["traffic"] <= 1.1 * k["compulsory_bytes"], "the dominant kernel moves what it must, not more"
+    else:
+        assert roof["traffic"] is None
     # the whole-pass algorithmic bytes are the contract's: 4380 B/point forward, 8504 B/point + F backward
     npts, F = 32 * 600 * 4, 32 * 6 * 14960 * 64 * 4
     assert abs(r["step_alg_GBps"] * r["ms_per_step"] * 1e6 - (npts * (4380 + 8504) + F)) <= 1e-6 * F
@@ -127,13 +155,19 @@ def test_build_then_smoke_in_one_process():
 
 
 @pytest.mark.gpu
-def test_two_real_ranks_on_one_device():
+@pytest.mark.parametrize("workload", ["T-fwdbwd", "train-M"])
+def test_two_real_ranks_on_one_device(workload):
     """The multi-rank path with real kernels: two ranks started by bench.py itself, both on this
-    box's one GPU, gloo (host tensors only) for the rendezvous, barriers and the slowest rank's time.
-    (The gradient all-reduce of train-M is rehearsed under gloo with the compute stubbed, on CPUs:
-    gloo reducing device tensors of a GPU that two ranks share hung once in three runs.)"""
+    box's one GPU, gloo for the rendezvous, barriers and the slowest rank's time - and, for train-M,
+    for the bucketed gradient all-reduce issued layer by layer.  gloo is given HOST tensors only
+    (reducing device tensors of a GPU that two ranks share hung once in three runs), and the
+    launcher ends ranks that are still running at its deadline."""
     r = run_bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3", "--warmup", "1",
-                  "--settle-ms", "20", "--workload", "T-fwdbwd", "--no-cpu-baseline", timeout=100)
+                  "--settle-ms", "20", "--workload", workload, "--no-cpu-baseline", "--event-steps", "2",
+                  "--rank-timeout", "80", timeout=100)
+    if workload == "train-M":
+        assert r["config"]["allreduce_schedule"] == [[layer, 2 * layer + k] for layer in range(6) for k in range(2)]
+        assert r["allreduce_exposed_us"] is not None
     assert r["n_gpus"] == 2 and r["config"]["shared_device"] is True and r["config"]["backend"] == "gloo"
     ranks = r["config"]["ranks"]
     assert [x["rank"] for x in ranks] == [0, 1] and ranks[0]["seed"] != ranks[1]["seed"]

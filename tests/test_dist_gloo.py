@@ -121,6 +121,11 @@ def test_bench_split_sample_and_allreduce_stubbed():
     r = _bench_line(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-compute",
                      "--workload", "train-M"])
     assert r["config"]["points_per_step_per_gpu"] == 6 * 32 * 2400 * 2 and r["n_gpus"] == 2
+    # two buckets are handed to the collective after each of the six layers' backward, in layer order
+    # (not all twelve behind the whole step), and the cost of the collective is reported
+    assert r["config"]["allreduce_schedule"] == [[layer, 2 * layer + k] for layer in range(6) for k in range(2)]
+    assert r["config"]["allreduce_bytes_per_step"] == 300 * 1000 * 1000
+    assert r["allreduce_exposed_us"] is not None and r["ms_per_step_without_allreduce"] >= 4.0
 
 
 def test_bench_rejects_a_world_size_that_contradicts_gpus():
@@ -144,3 +149,77 @@ def test_spawn_ranks_reports_a_failing_rank():
         assert spawn_ranks(2, [f.name]) == 7          # rank 1 fails; rank 0 (asleep) is terminated, not awaited
     finally:
         os.unlink(f.name)
+
+
+def _rank_script(code):
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+    return f.name
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    # a zombie still answers signal 0: look at its state
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_spawn_ranks_ends_a_rank_that_never_returns(tmp_path):
+    """A rank stuck for ever (here: asleep, and deaf to SIGTERM like a process blocked in a driver
+    call) must not hold the launcher: after the deadline it is terminated, then killed, and the
+    launcher returns 124 with no child left behind."""
+    import time
+    from opus_amd.dist import spawn_ranks
+    pidfile = tmp_path / "pids"
+    code = ("import os, signal, sys, time\n"
+            "r = int(os.environ['RANK'])\n"
+            f"open({str(pidfile)!r}, 'a').write(str(os.getpid()) + '\\n')\n"
+            "if r == 1:\n"
+            "    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+            "    time.sleep(600)\n"
+            "sys.exit(0)\n")
+    name = _rank_script(code)
+    try:
+        t0 = time.monotonic()
+        assert spawn_ranks(2, [name], timeout_s=3.0, grace_s=1.0) == 124
+        assert time.monotonic() - t0 < 30
+        pids = [int(x) for x in pidfile.read_text().split()]
+        assert len(pids) == 2 and not any(_alive(p) for p in pids)
+    finally:
+        os.unlink(name)
+
+
+def test_spawn_ranks_leaves_no_child_behind_when_interrupted(tmp_path):
+    """An exception in the launcher (KeyboardInterrupt while it polls) ends the ranks it started."""
+    import subprocess
+    import sys
+    import time
+    pidfile = tmp_path / "pids"
+    rank = _rank_script("import os, time\n"
+                        f"open({str(pidfile)!r}, 'a').write(str(os.getpid()) + '\\n')\n"
+                        "time.sleep(600)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    parent = ("import sys\n"
+              f"sys.path.insert(0, {root!r})\n"
+              "from opus_amd.dist import spawn_ranks\n"
+              f"sys.exit(spawn_ranks(2, [{rank!r}], timeout_s=600, grace_s=1.0))\n")
+    try:
+        p = subprocess.Popen([sys.executable, "-c", parent])
+        for _ in range(300):
+            if pidfile.exists() and len(pidfile.read_text().split()) == 2:
+                break
+            time.sleep(0.1)
+        import signal
+        p.send_signal(signal.SIGINT)
+        p.wait(timeout=60)
+        pids = [int(x) for x in pidfile.read_text().split()]
+        assert len(pids) == 2 and not any(_alive(q) for q in pids)
+    finally:
+        os.unlink(rank)

@@ -20,6 +20,9 @@ import shutil
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.buildinfo import csrc_hash  # noqa: E402
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 workload = sys.argv[2] if len(sys.argv) > 2 else "L-fwdbwd"
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -70,7 +73,11 @@ for k, cs in summary.items():
     if "TCC_HIT_sum" in cs:
         cs["l2_hit_rate"] = cs["TCC_HIT_sum"] / (cs["TCC_HIT_sum"] + cs["TCC_MISS_sum"])
     # the bench's record of a kernel: bytes per launch, the kernel instance they were measured on
-    traffic[{"msmv_fwd_sorted_c64": "msmv_fwd_sorted"}.get(k, k)] = {
+    # (bench.py's name of the kernel in this workload)
+    bench_name = {"msmv_fwd_sorted_c64": "msmv_fwd_sorted"}.get(k, k)
+    if k == "msmv_bwd_owner_dfeat" and (workload.startswith("decoder-") or workload == "train-M" or workload.startswith("chain-")):
+        bench_name = "msmv_bwd_owner_dfeat(6 layers)"
+    traffic[bench_name] = {
         "bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "template": template.get(k),
         **({"l2_hit_rate": cs["l2_hit_rate"]} if "l2_hit_rate" in cs else {})}
 summary["_fetch_size_scale"] = fetch_scale
@@ -80,8 +87,11 @@ json.dump(summary, open(os.path.join(dst, f"{out_tag}_pmc.json"), "w"), indent=1
 tpath = os.path.join(dst, "traffic.json")
 allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
 allt.pop(workload, None)                 # (records of earlier rounds were keyed by the workload alone)
+# the kernel sources the passes ran on: bench.py ignores the record once they change
+traffic["_csrc_sha256"] = csrc_hash()
+traffic["_profile"] = f"profiles/{out_tag}_pmc.json"
 allt[f"{workload}|batch={batch}|points={points}"] = traffic
-allt["_source"] = ("profiles/r02*_pmc.json (rocprofv3 --pmc passes of bench.py on exactly the keyed configuration, "
+allt["_source"] = ("profiles/*_pmc.json (rocprofv3 --pmc passes of bench.py on exactly the keyed configuration, "
                    "see tools/collect_profiles.sh); bytes cross the L2 <-> fabric boundary, Infinity-Cache hits included")
 json.dump(allt, open(tpath, "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1))
