@@ -64,7 +64,11 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="L-fwdbwd",
                     help="{T,S,M,L}-fwd | {T,S,M,L}-fwdbwd | decoder-{T,S,M,L} (6 layers fwd+bwd) | "
                          "train-M (6 x (2 fwd + 1 bwd) + RCCL all-reduce of a 0.3 GB gradient) | "
-                         "sampling4d-{T,S,M,L} (projection + op in the caller's layout, fwd+bwd)")
+                         "sampling4d-{T,S,M,L} (projection + op in the caller's layout, fwd+bwd) | "
+                         "chain-{T,S,M,L} (the decoder's whole sampling chain in training: feature re-layout, 6 x "
+                         "(projection + bin-ordered forward, both again for the checkpoint's recomputation, "
+                         "d loc / d w gather, projection backward), one d-feat pass over the 6 layers, inverse "
+                         "re-layout) | infer-{T,S,M,L} (re-layout + 6 x (projection + forward))")
     ap.add_argument("--points", default="uniform", choices=["uniform", "cameras", "queries"],
                     help="uniform: u,v ~ U(0,1), view ~ U{0..5} (every corner in range: the byte count is "
                          "exact); cameras: 3-D points in the occupancy range projected into a ring of 6 "
@@ -78,10 +82,10 @@ def parse_args(argv=None):
                     help="decoder workloads: how the layers' d feats are summed - 'deferred': every layer sorts "
                          "and gathers, one d-feat pass over all layers at the end writes d feats once; "
                          "'accumulate': the first layer's backward writes them, the others add to them")
-    ap.add_argument("--fwd-order", default="bin", choices=["bin", "input"],
+    ap.add_argument("--fwd-order", default=None, choices=["bin", "input"],
                     help="caller-layout workloads (sampling4d-*): 'bin' sorts the points once per layer and runs "
                          "the forward in bin order, the backward re-using the sort; 'input': forward in input "
-                         "order, the backward sorts for itself")
+                         "order, the backward sorts for itself (default: bin, input for infer-*)")
     ap.add_argument("--split-sample", action="store_true",
                     help="single-sample latency mode: the 32*batch slabs are split across the ranks (strong "
                          "scaling, still no data-path collective) instead of one whole batch per rank")
@@ -255,14 +259,22 @@ def compulsory_bytes(npts, feat_bytes, uniq, n_layers):
         "msmv_bwd_atomic(accumulate)": 2 * uniq + npts * (vec + 2 * small),
         "msmv_project_pack": npts * small * 2,
         "msmv_project_pack_bwd": npts * (small * 2 + 12 + 12),
+        # every feature (or d-feat) byte read once and written once
+        "msmv_relayout(4 levels)": 2 * feat_bytes,
+        "msmv_relayout(4 levels, inverse)": 2 * feat_bytes,
     }
 
 
 class Step:
     """One decoder layer's forward (+ backward) with an event pair around every launch."""
 
-    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1, caller=None, defer=False, fwd_sorted=False):
+    def __init__(self, feats, sets, do_bwd, algo, n_fwd=1, caller=None, defer=False, fwd_sorted=False, backbone=None):
         self.feats, self.sets, self.do_bwd, self.n_fwd = feats, sets, do_bwd, n_fwd
+        # backbone = the feature maps as the backbone emits them, [B, T*N, G*C, H, W] per level: the
+        # step then begins with their re-layout into `feats` (models/opus_transformer.py:113-126) and,
+        # with a backward, ends with the inverse re-layout of the d feats
+        self.backbone = backbone
+        self.dbackbone = [torch.empty_like(b) for b in backbone] if backbone and do_bwd else None
         self.algo = algo
         # deferred d feats: every layer sorts and gathers into a workspace of its own, one
         # d-feat pass over all layers closes the step (opus_msmv_dfeat_multi)
@@ -307,6 +319,8 @@ class Step:
         """`after_backward(layer)` is called when a layer's backward launches have been issued (the
         training workload hands the layer's gradient buckets to the all-reduce there)."""
         self._boundary = None
+        if self.backbone:
+            self._timed("msmv_relayout(4 levels)", lambda: self._relayout(self.backbone, self.feats, 0), record)
         for layer, (loc, w, g) in enumerate(self.sets):
             # layers of one decoder sample the same feature maps: the first backward writes
             # d feats, the others add to it (no zero-fill, no separate add pass)
@@ -375,6 +389,16 @@ class Step:
                 self._timed(f"msmv_bwd_owner_dfeat({len(part)} layers)", lambda: wrapper.msmv_dfeat_multi(
                     [self.sets[k][2] for k in part], [self.ws_per_layer[k] for k in part], self.feats, Q, P,
                     self.dfeats, rows=self.rows, accumulate=i > 0), record)
+
+        if self.dbackbone:
+            self._timed("msmv_relayout(4 levels, inverse)", lambda: self._relayout(self.dfeats, self.dbackbone, 1), record)
+
+    def _relayout(self, src, dst, inverse):
+        T, G = self.rows
+        for a, b in zip(src, dst):
+            raw = b if inverse else a                         # the backbone-layout tensor of the pair
+            B, TN, GC, H, W = raw.shape
+            opus_sampling._Relayout._run(a, b, (B, T, TN // T, G, GC // G, H, W), inverse)
 
     def kernel_ms(self):
         """name -> (mean, launches, p10, p50, p90) in ms."""
@@ -545,7 +569,14 @@ def main():
     # ---- workload
     wl = args.workload
     n_layers, n_fwd, allreduce_bytes = 1, 1, 0
-    if wl.startswith("decoder-"):
+    chain = wl.startswith("chain-") or wl.startswith("infer-")
+    if chain:
+        # the decoder's sampling chain (models/opus_transformer.py:113-136, 372-378): re-layout once,
+        # six layers; in training every layer's forward runs twice (activation checkpointing)
+        variant, do_bwd, n_layers = wl.split("-")[1], wl.startswith("chain-"), 6
+        n_fwd = 2 if do_bwd else 1
+        assert variant in VARIANTS, wl
+    elif wl.startswith("decoder-"):
         variant, do_bwd, n_layers = wl.split("-")[1], True, 6
         assert variant in VARIANTS, wl
     elif wl == "train-M":
@@ -572,15 +603,21 @@ def main():
         step, feats, sets = StubStep(rank, n_layers), [], []
     else:
         feats, sets = make_inputs(Bp, Q, P, seed, device, n_sets=n_layers)
-        if args.points != "uniform" or wl.startswith("sampling4d-"):
+        backbone = None
+        if args.points != "uniform" or wl.startswith("sampling4d-") or chain:
             cam = camera_sets(Bp, Q, P, seed, device, n_layers, from_queries=args.points == "queries")
             for (loc, w, g), (pts, sw, occ2img) in zip(sets, cam):
                 opus_sampling.project_pack_into(pts, sw, occ2img, 256, 704, N_VIEWS, loc, w)
-            if wl.startswith("sampling4d-"):
+            if wl.startswith("sampling4d-") or chain:
                 caller = cam
                 sets = [(loc, w, g.reshape(args.batch, Q, 4, 8 * P, CHANNELS)) for loc, w, g in sets]
+        if chain:
+            gen = torch.Generator(device=device).manual_seed(seed + 77)
+            backbone = [torch.randn((args.batch, 8 * N_VIEWS, 4 * CHANNELS, h, w_), generator=gen, device=device)
+                        for h, w_ in LEVELS]
+        fwd_order = args.fwd_order or ("input" if wl.startswith("infer-") else "bin")
         step = Step(feats, sets, do_bwd, args.bwd_algo, n_fwd=n_fwd, caller=caller, defer=args.dfeat == "deferred",
-                    fwd_sorted=args.fwd_order == "bin")
+                    fwd_sorted=fwd_order == "bin", backbone=backbone)
     npts_step = Bp * Q * P * n_layers                    # sampled points per step per rank
     feat_bytes = sum(f.numel() * 4 for f in feats)
 
@@ -753,7 +790,8 @@ def main():
                                    f"{'projection + op in the caller layout, ' if caller else ''}"
                                    f"{'forward + backward' if do_bwd else 'forward'}"
                                    f"{', %d decoder layers' % n_layers if n_layers > 1 else ''}"
-                                   f"{', 2 forwards per backward + gradient all-reduce' if wl == 'train-M' else ''}",
+                                   f"{', 2 forwards per backward + gradient all-reduce' if wl == 'train-M' else ''}"
+                                   f"{', with the feature re-layout' + (', 2 forwards per backward (activation checkpointing), d feats back in the backbone layout' if do_bwd else '') if chain else ''}",
                        "name": wl, "Q": Q, "P": P, "slabs_per_gpu": Bp, "views": N_VIEWS,
                        "levels": LEVELS, "channels": CHANNELS, "batch_per_gpu": args.batch,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,

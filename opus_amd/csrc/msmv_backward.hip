@@ -550,6 +550,9 @@ typedef __attribute__((address_space(3))) void *msmv_lptr_t;
 #ifndef MSMV_OWN_NT_STORE
 #define MSMV_OWN_NT_STORE 1
 #endif
+#ifndef MSMV_OWN_ROWS_NT_MULTI
+#define MSMV_OWN_ROWS_NT_MULTI 0                 // several point sets: gradient rows copied with the streaming hint
+#endif
 #ifndef MSMV_OWN_STAGE_F4
 #define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave: with the queue, LDS never limits the occupancy
 #endif
@@ -585,11 +588,16 @@ __device__ __forceinline__ float msmv_load_stream(const float *p)
 // clobbered, keeps nothing in it in these kernels.)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+template <bool STREAM = false>
 __device__ __forceinline__ void msmv_load_to_lds_b128(const float *src, const float4 *dst)
 {
     const unsigned lds = (unsigned)(uintptr_t)(msmv_lptr_t)dst;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(src), "s"(lds) : "memory", "m0");
+    if constexpr (STREAM)         // streaming hint: the copy does not displace what the L2 holds
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                     :: "v"(src), "s"(lds) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"(lds) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
@@ -976,7 +984,7 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
                                 go = gout_tab[__float_as_int(queue[rec * REC_DW + 1])];
                             const int row = PT == 4 ? rpt >> 2 : PT == 2 ? rpt >> 1 : rpt;
                             const float *src = go + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
-                            msmv_load_to_lds_b128(src, stage + (v % NS) * UNIT_F4 + j * 64);
+                            msmv_load_to_lds_b128<MULTI && MSMV_OWN_ROWS_NT_MULTI>(src, stage + (v % NS) * UNIT_F4 + j * 64);
                         }
                     };
                     // what the applying lane needs of unit v's records: its weight per pair and, for

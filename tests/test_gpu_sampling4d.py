@@ -828,3 +828,62 @@ def test_bin_ordered_forward_and_backward_on_its_sort_replay_from_a_hip_graph(op
     assert torch.equal(dloc, dl_ref) and torch.equal(dw_, dw_ref)
     for i, (a, b) in enumerate(zip(dfeats, df_ref)):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-5, f"replayed dfeat{i}")
+
+
+@pytest.mark.parametrize("workload", ["chain", "infer"])
+def test_bench_chain_workloads_equal_the_tensor_op_chain(ops, workload):
+    """bench.py's chain-* / infer-* steps - re-layout, six layers of projection + forward (twice in
+    training) + gather + projection backward, one d-feat pass, inverse re-layout, all as raw
+    launches through the C ABI - at a reduced query count against the same chain written with
+    tensor ops and autograd (the reference's formulation, models/opus_transformer.py:113-136 and
+    models/opus_sampling.py:19-124, around the plain op)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    bench.load_product()
+    Q, P, T, G, N, C, n_layers = 48, 2, 8, 4, 6, 64, 6
+    train = workload == "chain"
+    device = torch.device("cuda", 0)
+    feats, sets = bench.make_inputs(T * G, Q, P, 5, device, n_sets=n_layers)
+    cam = bench.camera_sets(T * G, Q, P, 5, device, n_layers)
+    sets = [(loc, w, g.reshape(1, Q, G, T * P, C)) for loc, w, g in sets]
+    gen = torch.Generator(device=device).manual_seed(9)
+    backbone = [torch.randn((1, T * N, G * C, h, w), generator=gen, device=device) for h, w in bench.LEVELS]
+    step = bench.Step(feats, sets, train, "owner", n_fwd=2 if train else 1, caller=cam, defer=True,
+                      fwd_sorted=train, backbone=backbone)
+    outs = []
+    if not train:
+        # the forward writes into a fresh tensor per call: keep every layer's output
+        from opus_amd.csrc import wrapper as wr
+        orig = wr.msmv_forward
+        wr.msmv_forward = lambda *a, **k: outs.append(orig(*a, **k)) or outs[-1]
+        try:
+            step.run(False)
+        finally:
+            wr.msmv_forward = orig
+    else:
+        step.run(False)
+    torch.cuda.synchronize()
+
+    raw = [b.clone().requires_grad_(train) for b in backbone]
+    f_ref = ops.relayout_features_torch(raw, T, N, G)
+    for a, b in zip(step.feats, f_ref):
+        assert torch.equal(a, b.detach()), "re-layout"
+    total, last = 0, None
+    for k, ((_, _, g), (pts, sw, occ2img)) in enumerate(zip(sets, cam)):
+        p = pts.clone().requires_grad_(train)
+        s_ = sw.clone().requires_grad_(train)
+        out = ops.sampling_4d(p, f_ref, s_, occ2img, 256, 704, N, fused=False)
+        if train:
+            total = total + (out * g).sum()
+            last = (p, s_)
+        else:
+            assert_close(outs[k].cpu().numpy(), out.detach().cpu().numpy(), FWD_RTOL, f"layer {k} output")
+    if train:
+        total.backward()
+        for i, (a, b) in enumerate(zip(step.dbackbone, raw)):
+            assert_close(a.cpu().numpy(), b.grad.cpu().numpy(), GRAD_RTOL, f"d backbone feat {i}")
+        assert_close(step.dpts.cpu().numpy(), last[0].grad.cpu().numpy(), GRAD_RTOL, "d sample_points (last layer)")
+        assert_close(step.dsw.cpu().numpy(), last[1].grad.cpu().numpy(), GRAD_RTOL, "d scale_weights (last layer)")
