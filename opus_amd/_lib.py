@@ -23,6 +23,7 @@ MAX_LEVELS = 8
 MAX_POINTS = 32
 NOALLOC_SCRATCH_BYTES = 32 << 20
 ESCRATCH = -9
+EINVAL_FLAGS = -7        # the call's form does not apply to these shapes / pointers (or unknown flag bits)
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i32p = ctypes.POINTER(ctypes.c_int)
@@ -40,6 +41,11 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
+    "opus_msmv_forward_queries_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
+    "opus_msmv_forward_queries": (ctypes.c_int, [
+        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _i32p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_backward": (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), _i32p,
         ctypes.c_void_p, ctypes.c_void_p,

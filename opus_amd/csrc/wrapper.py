@@ -67,7 +67,9 @@ if _bwd_algo not in _BWD_ALGOS:
 
 
 # Bin-ordered forward (opus_msmv_forward_sorted) in the autograd Functions that can use it (row
-# mode and P == 1, owner backward): the sort made for the forward is kept and serves the backward.
+# mode and P == 1, owner backward, some input needs a gradient): the sort made for the forward is
+# kept and serves the backward.  With several points per query in the op's own layout the forward
+# walks the queries in image order instead (opus_msmv_forward_queries), gradients or not.
 _fwd_sorted = os.environ.get("OPUS_MSMV_FWD_SORTED", "1") not in ("", "0")
 
 
@@ -189,6 +191,8 @@ def msmv_forward_sorted(feats, loc, w, rows=None, workspace=None, presorted=Fals
     lib = _lib.load()
     if rows is None and P != 1:
         return None
+    if not _aligned16(w, *feats):               # (what the library would refuse, before anything is allocated)
+        return None
     need = lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, _lib.BWD_OWNER)
     if need == 0:
         return None
@@ -207,9 +211,37 @@ def msmv_forward_sorted(feats, loc, w, rows=None, workspace=None, presorted=Fals
             L, _lib.ptr_array([f.data_ptr() for f in feats]), _lib.int_array(hw), loc.data_ptr(), w.data_ptr(),
             *dims, C, N, Q, P, out.data_ptr(), workspace.data_ptr(), workspace.numel(),
             _lib.FWD_PRESORTED if presorted else 0, _stream_ptr(loc.device))
-    if rc == -7:                                # EINVAL_FLAGS: shape / alignment the sort does not take
+    if rc == _lib.EINVAL_FLAGS and not presorted:     # a shape the sort does not take (e.g. more than 16 views)
         return None
     _lib.check(rc, "opus_msmv_forward_sorted")
+    return out, workspace
+
+
+def _aligned16(*tensors):
+    return all(t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def msmv_forward_queries(feats, loc, w, workspace=None, presorted=False):
+    """Forward in the op's own [B,Q,C,P] layout with the queries walked in image order
+    (opus_msmv_forward_queries) -> (out, workspace), or None where that form does not apply (then
+    use msmv_forward).  ``out`` is bit-identical to msmv_forward's.  The workspace holds the query
+    order (B*Q ints): hand it back with ``presorted=True`` for another forward on the same loc."""
+    L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
+    if C != 64 or L not in (4, 5) or P not in (2, 4) or N > 16 or not _aligned16(w, *feats):
+        return None
+    lib = _lib.load()
+    need = lib.opus_msmv_forward_queries_workspace_bytes(B, Q)
+    with torch.cuda.device(loc.device):
+        if workspace is None:
+            if presorted:
+                raise RuntimeError("presorted=True needs the workspace that holds the query order")
+            workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=loc.device)
+        out = torch.empty((B, Q, C, P), dtype=torch.float32, device=loc.device)
+        rc = lib.opus_msmv_forward_queries(
+            L, _lib.ptr_array([f.data_ptr() for f in feats]), _lib.int_array(hw), loc.data_ptr(), w.data_ptr(),
+            B, C, N, Q, P, out.data_ptr(), workspace.data_ptr(), workspace.numel(),
+            _lib.FWD_PRESORTED if presorted else 0, _stream_ptr(loc.device))
+    _lib.check(rc, "opus_msmv_forward_queries")
     return out, workspace
 
 
@@ -314,11 +346,18 @@ class _MSMVSampling(torch.autograd.Function):
         *feats, sampling_locations, scale_weights = args
         ctx.save_for_backward(*feats, sampling_locations, scale_weights)
         ctx.sorted_ws = None
-        if _fwd_sorted and _bwd_algo != "atomic":
+        # the point sort pays for itself only where a backward will use it too (it is kept, 32 bytes
+        # per point, until the graph is freed); without gradients the input-order kernel is as fast
+        if _fwd_sorted and _bwd_algo != "atomic" and any(ctx.needs_input_grad):
             res = msmv_forward_sorted(feats, sampling_locations, scale_weights)
             if res is not None:
                 out, ctx.sorted_ws = res
                 return out
+        if _fwd_sorted:
+            # several points per query: the queries in image order (a short-lived 4-byte-per-query order)
+            res = msmv_forward_queries(feats, sampling_locations, scale_weights)
+            if res is not None:
+                return res[0]
         return msmv_forward(feats, sampling_locations, scale_weights)
 
     @staticmethod
@@ -354,7 +393,7 @@ class MSMVSamplingRows(torch.autograd.Function):
         ctx.save_for_backward(*feats, sampling_locations, scale_weights)
         ctx.rows = (T, G)
         ctx.sorted_ws = None
-        if _fwd_sorted and _bwd_algo != "atomic":
+        if _fwd_sorted and _bwd_algo != "atomic" and any(ctx.needs_input_grad):
             res = msmv_forward_sorted(feats, sampling_locations, scale_weights, rows=ctx.rows)
             if res is not None:
                 out, ctx.sorted_ws = res
@@ -465,6 +504,10 @@ class _MSMVSamplingSink(torch.autograd.Function):
             if res is not None:
                 out, ctx.sorted_ws = res
                 return out
+        if _fwd_sorted and rows is None:
+            res = msmv_forward_queries(sink.feats, sampling_locations, scale_weights)
+            if res is not None:
+                return res[0]
         return msmv_forward(sink.feats, sampling_locations, scale_weights, rows=rows)
 
     @staticmethod

@@ -880,7 +880,14 @@ def test_bench_chain_workloads_equal_the_tensor_op_chain(ops, workload):
             total = total + (out * g).sum()
             last = (p, s_)
         else:
-            assert_close(outs[k].cpu().numpy(), out.detach().cpu().numpy(), FWD_RTOL, f"layer {k} output")
+            # the tensor-op projection sums its 4x4 products in the BLAS library's order, the kernel in
+            # the reference statement's: coordinates agree to 1e-6, which levels up to 176 pixels wide
+            # turn into 1e-4 of a pixel - hence the gradient bar here; the step's own projection through
+            # the plain op and the reference's permute must give the very same bits
+            assert_close(outs[k].cpu().numpy(), out.detach().cpu().numpy(), GRAD_RTOL, f"layer {k} output")
+            from opus_amd.csrc import wrapper as wr
+            loc_k, w_k, _ = sets[k]
+            assert torch.equal(outs[k], ops.unpack(wr.msmv_forward(step.feats, loc_k, w_k), 1, T, G)), f"layer {k}: row mode"
     if train:
         total.backward()
         for i, (a, b) in enumerate(zip(step.dbackbone, raw)):
