@@ -225,8 +225,6 @@ def alg_bytes(npts, feat_bytes):
     small = 12 + 4 * L                        # loc + weights (or their gradients)
     return {
         "msmv_fwd_c64": npts * (corner + vec + small),
-        "msmv_fwd_c64(query order)": npts * (corner + vec + small),
-        "msmv_qsort+fwd_c64": npts * (corner + vec + small),
         "msmv_fwd_sorted": npts * (corner + vec + small),
         "msmv_sort+fwd_sorted": npts * (corner + vec + small),
         "msmv_bwd_owner_dfeat": npts * (vec + small + corner) + feat_bytes,
@@ -250,9 +248,6 @@ def compulsory_bytes(npts, feat_bytes, uniq, n_layers):
     per_set = npts * (vec + entry)            # a layer's gradient rows + sorted entries
     return {
         "msmv_fwd_c64": uniq + npts * (vec + small),
-        # the order costs 4 bytes per query to read (and, where it is made, 12 + 4 more)
-        "msmv_fwd_c64(query order)": uniq + npts * (vec + small + 2),
-        "msmv_qsort+fwd_c64": uniq + npts * (vec + small + 2 + 8),
         "msmv_fwd_sorted": uniq + npts * (vec + entry),
         "msmv_sort+fwd_sorted": uniq + npts * (vec + entry) + npts * (small + entry),
         "msmv_bwd_owner_dfeat": feat_bytes + per_set,
@@ -291,14 +286,6 @@ class Step:
         # bin-ordered forward (row mode only): the layer's sort is made by its first forward and
         # serves its other forwards and its backward
         self.fwd_sorted = bool(fwd_sorted and caller and algo == "owner")
-        # the op's own layout with several points per query: the forward walks the QUERIES in image
-        # order (opus_msmv_forward_queries; the order, 4 bytes per query, is kept for the layer's
-        # second forward)
-        self.fwd_queries = bool(fwd_sorted and not caller and sets[0][0].shape[2] in (2, 4))
-        if self.fwd_queries:
-            B_, Q_ = sets[0][0].shape[:2]
-            nbytes = _lib.load().opus_msmv_forward_queries_workspace_bytes(B_, Q_)
-            self.qorder = [torch.empty(max(nbytes, 16), dtype=torch.uint8, device=sets[0][0].device) for _ in sets]
         loc, w, _ = sets[0]
         if caller:
             self.dpts = torch.empty_like(caller[0][0])
@@ -349,10 +336,6 @@ class Step:
                     self._timed("msmv_sort+fwd_sorted" if _ == 0 else "msmv_fwd_sorted",
                                 lambda pre=_ > 0: wrapper.msmv_forward_sorted(self.feats, loc, w, rows=rows, workspace=ws_l,
                                                                               presorted=pre), record)
-                elif self.fwd_queries:
-                    self._timed("msmv_qsort+fwd_c64" if _ == 0 else "msmv_fwd_c64(query order)",
-                                lambda pre=_ > 0: wrapper.msmv_forward_queries(self.feats, loc, w, workspace=self.qorder[layer],
-                                                                               presorted=pre), record)
                 else:
                     self._timed("msmv_fwd_c64", lambda: wrapper.msmv_forward(self.feats, loc, w, rows=rows), record)
             if not self.do_bwd:
@@ -813,8 +796,7 @@ def main():
                        "levels": LEVELS, "channels": CHANNELS, "batch_per_gpu": args.batch,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
                        "dfeat_sum": ("deferred" if step.defer else "accumulate") if n_layers > 1 and do_bwd else None,
-                       "fwd_order": ("bin" if getattr(step, "fwd_sorted", False) else
-                                     "queries by bin" if getattr(step, "fwd_queries", False) else "input"),
+                       "fwd_order": "bin" if getattr(step, "fwd_sorted", False) else "input",
                        "points": args.points if (not caller or args.points != "uniform") else "cameras",
                        "launch": ("HIP graph replay" if args.graph else
                                   "one call per kernel, no events inside the timed region"

@@ -199,28 +199,6 @@ int opus_msmv_forward_sorted(int L, const float *const *feats, const int *hw,
                              float *out, void *workspace, size_t workspace_bytes, int flags, void *stream);
 
 /*
- * Forward in the op's own [B,Q,C,P] layout with the QUERIES walked in image order: the queries of
- * every batch slab are first ordered by the image bin (view, y-band, x-band) of their first point
- * (one short launch, the order left in `workspace`), then the forward kernel of opus_msmv_forward
- * takes its queries from that order - a query's P points still together, as the [c][p] interleave of
- * the output needs.  Same arithmetic per point: `out` is bit-identical to opus_msmv_forward's; what
- * changes is the feature traffic (neighbouring work fetches neighbouring pixels).  No counterpart
- * in the reference (its kernel walks (b, q, c) in input order, msmv_sampling_forward.cu:96-101).
- *   workspace_bytes >= opus_msmv_forward_queries_workspace_bytes(B, Q), 16-byte aligned; nothing
- *   in it needs clearing.  flags: 0, or OPUS_MSMV_FWD_PRESORTED - `workspace` already holds the
- *   order of these very `loc` (an earlier call with the same sizes): the ordering launch is skipped.
- *   The workspace holds a query order, not the backward's point sort: it is no input to
- *   OPUS_MSMV_BWD_PRESORTED.
- * Returns OPUS_MSMV_EINVAL_FLAGS where this form does not apply (C != 64, L outside {4,5}, P outside
- * {2,4}, N > 16, pointers not 16-byte aligned): call opus_msmv_forward then.
- */
-size_t opus_msmv_forward_queries_workspace_bytes(int B, int Q);
-int opus_msmv_forward_queries(int L, const float *const *feats, const int *hw,
-                              const float *loc, const float *weights,
-                              int B, int C, int N, int Q, int P,
-                              float *out, void *workspace, size_t workspace_bytes, int flags, void *stream);
-
-/*
  * Deferred d feats for a stack of layers that sample the same feature maps (the decoder calls
  * the op once per layer, models/opus_transformer.py:57-75, and autograd sums the layers'
  * 735 MB d feats; nothing in a layer's own backward reads them).  No counterpart in the

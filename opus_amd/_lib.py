@@ -41,11 +41,6 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
-    "opus_msmv_forward_queries_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
-    "opus_msmv_forward_queries": (ctypes.c_int, [
-        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _i32p, ctypes.c_void_p, ctypes.c_void_p,
-        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "opus_msmv_backward": (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), _i32p,
         ctypes.c_void_p, ctypes.c_void_p,

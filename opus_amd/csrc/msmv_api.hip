@@ -179,50 +179,6 @@ int opus_msmv_forward_rows(int L, const float *const *feats, const int *hw,
     return forward_impl(L, feats, hw, loc, weights, Bs * T * G, T, G, C, N, Q, P, out, flags, stream);
 }
 
-size_t opus_msmv_forward_queries_workspace_bytes(int B, int Q)
-{
-    if (B < 0 || Q < 0)
-        return 0;
-    return (((size_t)B * (size_t)Q * sizeof(int)) + 255) & ~(size_t)255;
-}
-
-int opus_msmv_forward_queries(int L, const float *const *feats, const int *hw,
-                              const float *loc, const float *weights,
-                              int B, int C, int N, int Q, int P,
-                              float *out, void *workspace, size_t workspace_bytes, int flags, void *stream)
-{
-    MsmvArgs a = {};
-    const int rc = fill_common(a, L, hw, B, C, N, Q, P);
-    if (rc != OPUS_MSMV_OK)
-        return rc;
-    if (flags & ~OPUS_MSMV_FWD_PRESORTED)
-        return OPUS_MSMV_EINVAL_FLAGS;
-    if (!msmv_forward_query_order_supported(a) || !msmv_query_order_supported(a))
-        return OPUS_MSMV_EINVAL_FLAGS;
-    if (a.npts == 0)
-        return OPUS_MSMV_OK;
-    if (!feats || !loc || !weights || !out)
-        return OPUS_MSMV_EINVAL_PTR;
-    if (!aligned16(out) || !aligned16(weights))
-        return OPUS_MSMV_EINVAL_FLAGS;
-    for (int l = 0; l < L; ++l) {
-        if (!feats[l])
-            return OPUS_MSMV_EINVAL_PTR;
-        if (!aligned16(feats[l]))
-            return OPUS_MSMV_EINVAL_FLAGS;
-        a.lvl[l].feat = feats[l];
-    }
-    if (!workspace || workspace_bytes < opus_msmv_forward_queries_workspace_bytes(B, Q) || !aligned16(workspace))
-        return OPUS_MSMV_EWORKSPACE;
-    a.loc = loc;
-    a.w = weights;
-    a.out = out;
-    int *qorder = static_cast<int *>(workspace);
-    if (!(flags & OPUS_MSMV_FWD_PRESORTED) && msmv_launch_query_order(a, qorder, (hipStream_t)stream) != hipSuccess)
-        return OPUS_MSMV_ELAUNCH;
-    return msmv_launch_forward(a, (hipStream_t)stream, 0, qorder) == hipSuccess ? OPUS_MSMV_OK : OPUS_MSMV_ELAUNCH;
-}
-
 int opus_msmv_forward_sorted(int L, const float *const *feats, const int *hw,
                              const float *loc, const float *weights,
                              int Bs, int T, int G, int C, int N, int Q, int P,

@@ -431,50 +431,6 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
     }
 }
 
-// Order of a slab's QUERIES by the bin of their first point (for the forward in the op's own
-// [B,Q,C,P] layout with P > 1, where a query's points must stay together): one workgroup per batch
-// slab - LDS histogram over the keys, scan, placement through LDS cursors.  Writes query indices
-// b*Q + q; queries whose first point has no valid view fill the slab's slots from the last one down.
-__global__ void __launch_bounds__(BIN_THREADS)
-msmv_query_order(const MsmvArgs a, int *__restrict__ qorder)
-{
-    __shared__ int hist[BIN_MAX_KEYS];
-    __shared__ int incl[BIN_MAX_KEYS];
-    __shared__ int wave_tot[BIN_THREADS / 64];
-    __shared__ int tail_n;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const int keys = a.N * BIN_PER_VIEW;
-    const int Q = a.Q;
-    for (int k = tid; k < keys; k += BIN_THREADS)
-        hist[k] = 0;
-    if (tid == 0)
-        tail_n = 0;
-    __syncthreads();
-    const float *loc0 = a.loc + (size_t)b * a.qp * 3;            // the slab's first point
-    for (int q = tid; q < Q; q += BIN_THREADS) {
-        const int key = msmv_bin_key(loc0 + (size_t)q * a.P * 3, a.N);
-        atomicAdd(key >= 0 ? &hist[key] : &tail_n, 1);
-    }
-    __syncthreads();
-    for (int k = tid; k < keys; k += BIN_THREADS)
-        incl[k] = hist[k];
-    __syncthreads();
-    msmv_block_scan(incl, keys, wave_tot);
-    // hist becomes the next free slot of every key
-    for (int k = tid; k < keys; k += BIN_THREADS)
-        hist[k] = incl[k] - hist[k];
-    if (tid == 0)
-        tail_n = 0;
-    __syncthreads();
-    int *out = qorder + (size_t)b * Q;
-    for (int q = tid; q < Q; q += BIN_THREADS) {
-        const int key = msmv_bin_key(loc0 + (size_t)q * a.P * 3, a.N);
-        const int r = atomicAdd(key >= 0 ? &hist[key] : &tail_n, 1);
-        out[key >= 0 ? r : Q - 1 - r] = b * Q + q;
-    }
-}
-
 // ======================================================================================
 // owner algorithm: d feat tiles
 // ======================================================================================
@@ -1534,19 +1490,6 @@ hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool ac
     if (nblk < 1)
         nblk = 1;
     hipLaunchKernelGGL(msmv_bwd_atomic, dim3(nblk), dim3(64 * wpb), 0, s, a);
-    return msmv_launch_status(stale);
-}
-
-bool msmv_query_order_supported(const MsmvArgs &a)
-{
-    return a.N * BIN_PER_VIEW <= BIN_MAX_KEYS;
-}
-
-hipError_t msmv_launch_query_order(const MsmvArgs &a, int *qorder, hipStream_t s)
-{
-    const hipError_t stale = hipPeekAtLastError();
-    if (a.B > 0 && a.Q > 0)
-        hipLaunchKernelGGL(msmv_query_order, dim3((unsigned)a.B), dim3(BIN_THREADS), 0, s, a, qorder);
     return msmv_launch_status(stale);
 }
 

@@ -45,14 +45,9 @@ __device__ __forceinline__ float4 ld4_level(const float *p, bool stream)   // (c
     }
 }
 
-// QORD (PT in {2, 4}): the wave's queries are taken from `qorder`, a permutation of the query indices
-// b*Q + q that lists every batch slab's queries by the image bin of their first point
-// (msmv_launch_query_order), instead of in input order: the rows a CU works on at one time then fetch
-// neighbouring pixels, and a query's P points are still stored by one wave (the lane-row transposes
-// below need them together).  Per point the arithmetic is the same: outputs are bit-identical.
-template <int NL, int PT, bool QORD = false>
+template <int NL, int PT>
 __global__ void __launch_bounds__(FWD_THREADS)
-msmv_fwd_c64(const MsmvArgs a, const int *__restrict__ qorder)
+msmv_fwd_c64(const MsmvArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int sub = lane >> 4;        // which of the wave's 4 points
@@ -67,14 +62,8 @@ msmv_fwd_c64(const MsmvArgs a, const int *__restrict__ qorder)
         const int g = g0 + gi;
         if (g >= ngroups)
             break;                                   // wave-uniform
-        int pt_raw = g * 4 + sub;
+        const int pt_raw = g * 4 + sub;
         const bool act = pt_raw < a.npts;
-        if constexpr (QORD) {
-            static_assert(PT == 2 || PT == 4, "whole queries per wave");
-            // slot of the order -> query -> this row's point of it
-            const int slot = min(pt_raw, a.npts - 1) / PT;
-            pt_raw = qorder[slot] * PT + (sub & (PT - 1));
-        }
         const int pt = act ? pt_raw : a.npts - 1;    // keep addresses valid for idle rows
 
         const float *lp = a.loc + (size_t)pt * 3;
@@ -216,45 +205,31 @@ msmv_fwd_generic(const MsmvArgs a)
 }
 
 template <int NL>
-void launch_c64(const MsmvArgs &a, hipStream_t s, const int *qorder)
+void launch_c64(const MsmvArgs &a, hipStream_t s)
 {
     const int ngroups = (a.npts + 3) / 4;
     const int per_block = (FWD_THREADS / 64) * FWD_GROUPS_PER_WAVE;
     const int nblk = (ngroups + per_block - 1) / per_block;
-    const int *none = nullptr;
-    if (qorder && !a.rows && a.P == 2) {
-        hipLaunchKernelGGL((msmv_fwd_c64<NL, 2, true>), dim3(nblk), dim3(FWD_THREADS), 0, s, a, qorder);
-        return;
-    }
-    if (qorder && !a.rows && a.P == 4) {
-        hipLaunchKernelGGL((msmv_fwd_c64<NL, 4, true>), dim3(nblk), dim3(FWD_THREADS), 0, s, a, qorder);
-        return;
-    }
     switch (a.rows ? MSMV_PT_ROWS : a.P) {
-    case MSMV_PT_ROWS: hipLaunchKernelGGL((msmv_fwd_c64<NL, MSMV_PT_ROWS>), dim3(nblk), dim3(FWD_THREADS), 0, s, a, none); break;
-    case 1: hipLaunchKernelGGL((msmv_fwd_c64<NL, 1>), dim3(nblk), dim3(FWD_THREADS), 0, s, a, none); break;
-    case 2: hipLaunchKernelGGL((msmv_fwd_c64<NL, 2>), dim3(nblk), dim3(FWD_THREADS), 0, s, a, none); break;
-    case 4: hipLaunchKernelGGL((msmv_fwd_c64<NL, 4>), dim3(nblk), dim3(FWD_THREADS), 0, s, a, none); break;
-    default: hipLaunchKernelGGL((msmv_fwd_c64<NL, 0>), dim3(nblk), dim3(FWD_THREADS), 0, s, a, none); break;
+    case MSMV_PT_ROWS: hipLaunchKernelGGL((msmv_fwd_c64<NL, MSMV_PT_ROWS>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((msmv_fwd_c64<NL, 1>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((msmv_fwd_c64<NL, 2>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((msmv_fwd_c64<NL, 4>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
+    default: hipLaunchKernelGGL((msmv_fwd_c64<NL, 0>), dim3(nblk), dim3(FWD_THREADS), 0, s, a); break;
     }
 }
 
 }  // namespace
 
-bool msmv_forward_query_order_supported(const MsmvArgs &a)
-{
-    return a.C == 64 && (a.L == 4 || a.L == 5) && !a.rows && (a.P == 2 || a.P == 4);
-}
-
-hipError_t msmv_launch_forward(const MsmvArgs &a, hipStream_t s, int force_generic, const int *qorder)
+hipError_t msmv_launch_forward(const MsmvArgs &a, hipStream_t s, int force_generic)
 {
     if (a.npts == 0)
         return hipSuccess;
     const hipError_t stale = hipPeekAtLastError();
     if (!force_generic && a.C == 64 && a.L == 4) {
-        launch_c64<4>(a, s, qorder);
+        launch_c64<4>(a, s);
     } else if (!force_generic && a.C == 64 && a.L == 5) {
-        launch_c64<5>(a, s, qorder);
+        launch_c64<5>(a, s);
     } else {
         const int waves_per_block = 4;
         int nblk = (a.npts + waves_per_block - 1) / waves_per_block;

@@ -18,15 +18,7 @@ inline hipError_t msmv_launch_status(hipError_t stale)
 }
 
 // force_generic != 0 selects the any-shape kernel even when the fast path applies (testing).
-// qorder != nullptr (only where msmv_forward_query_order_supported): the queries are walked in that
-// order (see msmv_launch_query_order) instead of in input order; same outputs.
-hipError_t msmv_launch_forward(const MsmvArgs &a, hipStream_t s, int force_generic, const int *qorder = nullptr);
-bool msmv_forward_query_order_supported(const MsmvArgs &a);
-// qorder[b*Q .. (b+1)*Q) = the query indices b*Q + q of batch slab b ordered by the image bin (view,
-// y-band, x-band) of the query's first point; queries whose first point has no valid view come last.
-// Needs N * 256 <= 4096 bins (N <= 16).
-bool msmv_query_order_supported(const MsmvArgs &a);
-hipError_t msmv_launch_query_order(const MsmvArgs &a, int *qorder, hipStream_t s);
+hipError_t msmv_launch_forward(const MsmvArgs &a, hipStream_t s, int force_generic);
 
 // Atomic-scatter backward: clears d feats unless `accumulate`, then one wave per point.
 hipError_t msmv_launch_backward_atomic(const MsmvArgs &a, hipStream_t s, bool accumulate);

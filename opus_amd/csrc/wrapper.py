@@ -68,8 +68,7 @@ if _bwd_algo not in _BWD_ALGOS:
 
 # Bin-ordered forward (opus_msmv_forward_sorted) in the autograd Functions that can use it (row
 # mode and P == 1, owner backward, some input needs a gradient): the sort made for the forward is
-# kept and serves the backward.  With several points per query in the op's own layout the forward
-# walks the queries in image order instead (opus_msmv_forward_queries), gradients or not.
+# kept and serves the backward.
 _fwd_sorted = os.environ.get("OPUS_MSMV_FWD_SORTED", "1") not in ("", "0")
 
 
@@ -221,30 +220,6 @@ def _aligned16(*tensors):
     return all(t.data_ptr() % 16 == 0 for t in tensors)
 
 
-def msmv_forward_queries(feats, loc, w, workspace=None, presorted=False):
-    """Forward in the op's own [B,Q,C,P] layout with the queries walked in image order
-    (opus_msmv_forward_queries) -> (out, workspace), or None where that form does not apply (then
-    use msmv_forward).  ``out`` is bit-identical to msmv_forward's.  The workspace holds the query
-    order (B*Q ints): hand it back with ``presorted=True`` for another forward on the same loc."""
-    L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
-    if C != 64 or L not in (4, 5) or P not in (2, 4) or N > 16 or not _aligned16(w, *feats):
-        return None
-    lib = _lib.load()
-    need = lib.opus_msmv_forward_queries_workspace_bytes(B, Q)
-    with torch.cuda.device(loc.device):
-        if workspace is None:
-            if presorted:
-                raise RuntimeError("presorted=True needs the workspace that holds the query order")
-            workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=loc.device)
-        out = torch.empty((B, Q, C, P), dtype=torch.float32, device=loc.device)
-        rc = lib.opus_msmv_forward_queries(
-            L, _lib.ptr_array([f.data_ptr() for f in feats]), _lib.int_array(hw), loc.data_ptr(), w.data_ptr(),
-            B, C, N, Q, P, out.data_ptr(), workspace.data_ptr(), workspace.numel(),
-            _lib.FWD_PRESORTED if presorted else 0, _stream_ptr(loc.device))
-    _lib.check(rc, "opus_msmv_forward_queries")
-    return out, workspace
-
-
 def backward_workspace_bytes(feats, loc, w, flags=0):
     """Device scratch the backward needs for these tensors (0 for the atomic algorithm)."""
     L, B, C, N, Q, P, _ = _check_inputs(feats, loc, w)
@@ -353,11 +328,6 @@ class _MSMVSampling(torch.autograd.Function):
             if res is not None:
                 out, ctx.sorted_ws = res
                 return out
-        if _fwd_sorted:
-            # several points per query: the queries in image order (a short-lived 4-byte-per-query order)
-            res = msmv_forward_queries(feats, sampling_locations, scale_weights)
-            if res is not None:
-                return res[0]
         return msmv_forward(feats, sampling_locations, scale_weights)
 
     @staticmethod
@@ -504,10 +474,6 @@ class _MSMVSamplingSink(torch.autograd.Function):
             if res is not None:
                 out, ctx.sorted_ws = res
                 return out
-        if _fwd_sorted and rows is None:
-            res = msmv_forward_queries(sink.feats, sampling_locations, scale_weights)
-            if res is not None:
-                return res[0]
         return msmv_forward(sink.feats, sampling_locations, scale_weights, rows=rows)
 
     @staticmethod

@@ -676,46 +676,3 @@ def test_full_size_six_layer_decoder_step(wr, oracle, mode):
         total = df if total is None else [a + b for a, b in zip(total, df)]
     for i, d in enumerate(got):
         assert_close(d[sl].cpu().numpy(), total[i], GRAD_RTOL, f"dfeat{i} last slab, six layers [{mode}]")
-
-
-# ---- forward with the queries walked in image order (opus_msmv_forward_queries)
-@pytest.mark.parametrize("case", [
-    # levels, B, N, Q, P, share of out-of-range locations
-    (REAL_LEVELS, 3, 6, 701, 2, 0.25), (REAL_LEVELS, 2, 6, 333, 4, 0.25), (REAL_LEVELS, 1, 1, 50, 2, 0.0),
-    (TINY_LEVELS, 5, 16, 97, 2, 0.4), (REAL_LEVELS + [(4, 11)], 2, 3, 64, 4, 0.25), (REAL_LEVELS, 2, 6, 1, 2, 0.0),
-    (REAL_LEVELS, 2, 6, 5000, 2, 0.1),
-], ids=lambda c: "L%dB%dN%dQ%dP%d" % (len(c[0]), *c[1:5]))
-def test_query_ordered_forward_is_bit_identical(wr, case):
-    """Same arithmetic per point, another walk over the queries: every bit of the output equals
-    the input-order forward's, which the tests above hold against the oracle."""
-    levels, B, N, Q, P, oob = case
-    feats, loc, w, _ = random_case(4100 + Q, levels, B, N, 64, Q, P, oob)
-    loc[0, 0, :, 2] = 7.0                       # a query whose points have no valid view
-    if Q > 3:
-        loc[-1, 3, 0, 2] = np.nan               # ... and one whose first point has none, the others do
-    f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
-    ref = wr.msmv_forward(f, l, ww)
-    out, ws = wr.msmv_forward_queries(f, l, ww)
-    assert torch.equal(out, ref)
-    # the order is a permutation of every slab's queries
-    order = ws[: B * Q * 4].view(torch.int32).cpu().numpy().reshape(B, Q)
-    for b in range(B):
-        assert np.array_equal(np.sort(order[b]), np.arange(b * Q, (b + 1) * Q))
-    # again on the kept order, into a poisoned output
-    out2, _ = wr.msmv_forward_queries(f, l, ww, workspace=ws, presorted=True)
-    assert torch.equal(out2, ref)
-
-
-def test_query_ordered_forward_full_size_and_refusals(wr):
-    feats, loc, w, _ = random_case(4200, REAL_LEVELS, 32, 6, 64, 4800, 2, 0.05)
-    f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
-    out, _ = wr.msmv_forward_queries(f, l, ww)
-    assert torch.equal(out, wr.msmv_forward(f, l, ww))
-    # through the dispatcher (no gradients asked for): the same bits
-    assert torch.equal(wr.msmv_sampling(f, l, ww), out)
-    # forms it does not take: the caller runs the plain forward
-    for levels, C, P in ((REAL_LEVELS, 64, 3), (REAL_LEVELS, 64, 1), (TINY_LEVELS, 8, 2)):
-        fs, ls, ws_, _ = random_case(4201, levels, 2, 6, C, 20, P)
-        assert wr.msmv_forward_queries([dev(x) for x in fs], dev(ls), dev(ws_)) is None
-    fs, ls, ws_, _ = random_case(4202, TINY_LEVELS, 2, 17, 64, 20, 2)
-    assert wr.msmv_forward_queries([dev(x) for x in fs], dev(ls), dev(ws_)) is None      # more than 16 views

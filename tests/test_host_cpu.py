@@ -101,17 +101,6 @@ def test_argument_validation_returns_before_any_launch(lib):
     assert multi(4, 1, ptrs, ptrs, 0, real, 32, 0, 0, 64, 6, 10, 2, p4, 0, null) == -4      # null d feats
     assert multi(4, 1, ptrs, ptrs, 0, real, 4, 8, 0, 64, 6, 10, 2, p4, 0, null) == -3       # rows: G < 1
     assert multi(4, 1, ptrs, ptrs, 0, real, 0, 0, 0, 64, 6, 10, 2, p4, 0, null) == 0        # empty batch
-    # the query-ordered forward: 4 bytes per query of workspace; forms it does not take are EINVAL_FLAGS
-    fq, fq_ws = lib.opus_msmv_forward_queries, lib.opus_msmv_forward_queries_workspace_bytes
-    assert fq_ws(32, 4800) == 32 * 4800 * 4 and fq_ws(1, 1) == 256 and fq_ws(-1, 4) == 0
-    assert fq(4, p4, real, null, null, 32, 64, 6, 10, 3, null, null, 0, 0, null) == -7      # P outside {2, 4}
-    assert fq(4, p4, real, null, null, 32, 64, 6, 10, 1, null, null, 0, 0, null) == -7
-    assert fq(4, p4, real, null, null, 32, 8, 6, 10, 2, null, null, 0, 0, null) == -7       # C != 64
-    assert fq(4, p4, real, null, null, 32, 64, 17, 10, 2, null, null, 0, 0, null) == -7     # more than 16 views
-    assert fq(4, p4, real, null, null, 32, 64, 6, 10, 2, null, null, 0, 0x8, null) == -7    # unknown flag
-    assert fq(4, p4, real, null, null, 32, 64, 6, 10, 33, null, null, 0, 0, null) == -2
-    assert fq(4, p4, real, null, null, 32, 64, 6, 10, 2, null, null, 0, 0, null) == -4      # null data
-    assert fq(4, p4, real, null, null, 0, 64, 6, 10, 2, null, null, 0, 0, null) == 0        # empty batch
 
 
 def test_wrapper_mirrors_reference_names_and_checks():
