@@ -126,6 +126,15 @@ size_t opus_msmv_backward_workspace_bytes(int L, int B, int C, int N, int Q, int
  * zeros_like() clears the reference's host shim performs (msmv_sampling.cpp:244-249).
  * `workspace` must point to at least opus_msmv_backward_workspace_bytes(...) bytes of
  * device memory (may be NULL when that is 0); its contents on entry are ignored.
+ * Non-finite gradients: the reference adds w * g to the four corner pixels of a point only
+ * (msmv_sampling_backward.cu:60-99), so an inf / NaN in grad_out reaches those pixels.  The atomic
+ * algorithm does the same.  The owner algorithm accumulates a 4 x 8-pixel patch as one matrix
+ * product over the patch's points, zero weights included: a non-finite grad_out value of a point
+ * turns that channel of EVERY pixel of the patches the point's corners fall into (at every level)
+ * into inf / NaN, not just of the corner pixels, and may do the same to patches next to them (a
+ * patch reads the gradient rows of points in the image bins it scans, with weight zero where they
+ * miss it).  Other channels, other views and batch slabs, and d loc / d weights of other points are
+ * unaffected.
  */
 int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, const int *hw,
                        const float *loc, const float *weights,
@@ -140,8 +149,10 @@ int opus_msmv_backward(int L, const float *grad_out, const float *const *feats, 
  * opus_msmv_backward without `workspace` / `workspace_bytes`: the sort's scratch (histogram
  * table, offsets and the sorted point entries, opus_msmv_backward_workspace_bytes() bytes) lives in a
  * static device array of OPUS_MSMV_NOALLOC_SCRATCH_BYTES inside the library, one copy per GPU,
- * held until the process ends.  Sizes that need more return OPUS_MSMV_ESCRATCH (32 MiB covers
- * B*Q*P <= about 0.85 M points at N = 6, e.g. two OPUS-L samples); nothing is launched then.
+ * held until the process ends.  Sizes that need more (32 MiB covers B*Q*P <= about 0.85 M points
+ * at N = 6, e.g. two OPUS-L samples): with the owner algorithm asked for by name the call returns
+ * OPUS_MSMV_ESCRATCH and launches nothing; with OPUS_MSMV_BWD_AUTO it runs the atomic algorithm,
+ * which needs no scratch (what AUTO falls back to wherever the owner algorithm does not apply).
  * The call neither allocates nor frees nor synchronises.  The first call on a device looks the
  * array's address up (hipGetSymbolAddress, which may load the library's code object): make it
  * outside any graph capture.  All calls on one GPU share that GPU's array: calls that overlap

@@ -323,8 +323,14 @@ int opus_msmv_backward_noalloc(int L, const float *grad_out, const float *const 
 {
     // 0 where no scratch is needed (atomic algorithm, shapes the owner algorithm does not take)
     const size_t need = opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags);
-    if (need > OPUS_MSMV_NOALLOC_SCRATCH_BYTES)
+    if (need > OPUS_MSMV_NOALLOC_SCRATCH_BYTES) {
+        // the caller left the choice to the library: the atomic algorithm needs no scratch (it is what
+        // OPUS_MSMV_BWD_AUTO falls back to wherever the owner algorithm does not apply)
+        if ((flags & 0xF) == OPUS_MSMV_BWD_AUTO && !(flags & (OPUS_MSMV_BWD_STAGE_MASK | OPUS_MSMV_BWD_PRESORTED)))
+            return backward_impl(L, grad_out, feats, hw, loc, weights, B, 0, 0, C, N, Q, P, dfeats, dloc, dweights,
+                                 nullptr, 0, (flags & ~0xF) | OPUS_MSMV_BWD_ATOMIC, stream);
         return OPUS_MSMV_ESCRATCH;
+    }
     void *ptr = nullptr;
     const int rc = scratch_of_current_device(&ptr);
     if (rc != OPUS_MSMV_OK)

@@ -676,3 +676,39 @@ def test_full_size_six_layer_decoder_step(wr, oracle, mode):
         total = df if total is None else [a + b for a, b in zip(total, df)]
     for i, d in enumerate(got):
         assert_close(d[sl].cpu().numpy(), total[i], GRAD_RTOL, f"dfeat{i} last slab, six layers [{mode}]")
+
+
+def test_where_a_non_finite_gradient_lands(wr):
+    """An inf in grad_out of one valid point: the reference (and the atomic algorithm) carry it to
+    that point's corner pixels; the owner algorithm forms whole 4 x 8 patches as matrix products, so
+    the channel goes non-finite on the patches around the point - never on another channel, view or
+    batch slab - and everything that stays finite equals the atomic algorithm's result."""
+    B, N, C, Q, P = 2, 6, 64, 300, 2
+    feats, loc, w, gout = random_case(8800, REAL_LEVELS, B, N, C, Q, P, 0.0)
+    b0, q0, p0, ch = 1, 17, 1, 5
+    loc[b0, q0, p0] = (0.4, 0.6, 2 / (N - 1))
+    gout[b0, q0, ch, p0] = np.inf
+    f, l, ww, g = [dev(x) for x in feats], dev(loc), dev(w), dev(gout)
+    own = wr.msmv_backward(g, f, l, ww, algo="owner")
+    ato = wr.msmv_backward(g, f, l, ww, algo="atomic")
+    for lvl, (a, o) in enumerate(zip(ato[0], own[0])):
+        a, o = a.cpu().numpy(), o.cpu().numpy()
+        bad_a, bad_o = ~np.isfinite(a), ~np.isfinite(o)
+        assert bad_a.any() and (bad_o | ~bad_a).all(), f"level {lvl}: the corner pixels themselves"
+        where = np.argwhere(bad_o)                       # (b, view, y, x, channel)
+        assert (where[:, 0] == b0).all() and (where[:, 1] == 2).all() and (where[:, 4] == ch).all()
+        H, W = REAL_LEVELS[lvl]
+        y, x = 0.6 * (H - 1), 0.4 * (W - 1)
+        # within the patches that scan the point's image bin (a bin is 1/8 x 1/32 of the view, a patch
+        # 4 x 8 pixels and scans one pixel beyond its edges)
+        assert (np.abs(where[:, 2] - y) <= H / 8 + 6).all() and (np.abs(where[:, 3] - x) <= W / 32 + 10).all()
+        scale = np.abs(a[~bad_a]).max()
+        assert np.abs(a[~bad_o] - o[~bad_o]).max() <= GRAD_RTOL * scale
+    for a, o, what in ((ato[1], own[1], "dloc"), (ato[2], own[2], "dw")):
+        a, o = a.cpu().numpy(), o.cpu().numpy()
+        bad = ~np.isfinite(o)
+        assert np.array_equal(bad, ~np.isfinite(a)), what
+        only = np.zeros_like(bad)
+        only[b0, q0, p0] = True
+        assert not (bad & ~only).any(), f"{what}: other points stay finite"
+        assert_close(np.where(bad, 0, o), np.where(bad, 0, a), GRAD_RTOL, what)

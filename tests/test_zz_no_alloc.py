@@ -17,7 +17,7 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _both(lib_mod, wr, case, flags):
+def _both(lib_mod, wr, case, flags, ref_flags=None):
     """(reference entry point, no-alloc entry point) -> two (dfeats, dloc, dw) tuples, as numpy."""
     levels, B, N, C, Q, P, seed = case
     feats, loc, w, gout = random_case(seed, levels, B, N, C, Q, P, oob_frac=0.25)
@@ -37,10 +37,12 @@ def _both(lib_mod, wr, case, flags):
     # existing entry point, workspace from the caller
     df0, dl0, dw0 = fresh()
     need = lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, flags)
-    ws = torch.full((max(need, 16),), 0xFF, dtype=torch.uint8, device="cuda")
+    ref_flags = flags if ref_flags is None else ref_flags
+    ws = torch.full((max(lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, ref_flags), 16),), 0xFF,
+                    dtype=torch.uint8, device="cuda")
     rc = lib.opus_msmv_backward(L, g.data_ptr(), fptrs, hw, l.data_ptr(), ww.data_ptr(), B, C, N, Q, P,
                                 lib_mod.ptr_array([x.data_ptr() for x in df0]), dl0.data_ptr(), dw0.data_ptr(),
-                                ws.data_ptr(), ws.numel(), flags, stream)
+                                ws.data_ptr(), ws.numel(), ref_flags, stream)
     lib_mod.check(rc, "opus_msmv_backward")
 
     # the entry point that allocates nothing: torch's allocator must see no request during the call
@@ -104,7 +106,20 @@ def test_noalloc_backward_rejects_sizes_beyond_the_static_buffer():
     L, B, C, N, Q, P = 4, 128, 64, 6, 4800, 2            # 1.2 M points: 39 MB of sort entries
     assert lib.opus_msmv_backward_workspace_bytes(L, B, C, N, Q, P, 0) > lib_mod.NOALLOC_SCRATCH_BYTES
     hw = lib_mod.int_array([d for h_w in REAL_LEVELS for d in h_w])
-    # rejected before any pointer is looked at or anything is launched
-    rc = lib.opus_msmv_backward_noalloc(L, None, None, hw, None, None, B, C, N, Q, P, None, None, None, 0, None)
+    # the owner algorithm asked for by name: rejected before any pointer is looked at or anything is launched
+    rc = lib.opus_msmv_backward_noalloc(L, None, None, hw, None, None, B, C, N, Q, P, None, None, None,
+                                        lib_mod.BWD_OWNER, None)
     assert rc == lib_mod.ESCRATCH
     assert "scratch" in lib_mod.strerror(rc)
+
+
+def test_noalloc_backward_auto_falls_back_to_the_atomic_algorithm_beyond_the_buffer():
+    """With the choice of algorithm left to the library, sizes whose sort does not fit the static
+    array run the atomic algorithm (which needs no scratch) instead of failing."""
+    from opus_amd import _lib as lib_mod
+    from opus_amd.csrc import wrapper as wr
+    from helpers import TINY_LEVELS
+    case = (TINY_LEVELS, 64, 6, 64, 8400, 2, 303)            # 1.08 M points: 34 MB of sort entries
+    ref, got, need, _ = _both(lib_mod, wr, case, lib_mod.BWD_AUTO, ref_flags=lib_mod.BWD_ATOMIC)
+    assert need > lib_mod.NOALLOC_SCRATCH_BYTES
+    _compare(ref, got, "auto beyond the scratch size")
