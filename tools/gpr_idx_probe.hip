@@ -6,7 +6,10 @@
 //
 // Part 1 (semantics): every wave applies a list of hits {pixel index, 4 weights, gradient row} and
 // the result is compared with a host loop, bit for bit.
-// Part 2 (rate): the same loop over many hits per wave, full chip, cycles per hit per SIMD.
+// Part 2 (rate, only with --at-scale): the same loop over many hits per wave, full chip, cycles per hit
+// per SIMD.  CAUTION: kernels that hold index mode at full occupancy faulted the GPU on the
+// development machines (a product kernel built on this instruction, and MODE 5 here); the rate runs
+// of the other modes completed, unchecked.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -316,7 +319,11 @@ probe5(const Hit *hits, int nchunks, const float *rows, float *out, long long *c
 
 int main(int argc, char **argv)
 {
-    const int nrows = argc > 1 ? atoi(argv[1]) : 1 << 12;      // 1 MiB of rows: they stay in L2
+    // Index-mode kernels at full occupancy ended in NaN results and GPU memory faults on the machines
+    // this was developed on (the small checked runs never did): only the checked 8-wave runs are made
+    // unless the rate runs are asked for by name.
+    const bool at_scale = argc > 1 && strcmp(argv[1], "--at-scale") == 0;
+    const int nrows = 1 << 12;                                 // 1 MiB of rows: they stay in L2
     std::vector<float> rows((size_t)nrows * 64);
     srand(7);
     for (auto &x : rows)
@@ -328,6 +335,10 @@ int main(int argc, char **argv)
     static const int modes[] = {0, 2, 6, 7, 8, 5};
     for (int part = 0; part < 12; ++part) {
         const int mode = modes[part >> 1];
+        if ((part & 1) && !at_scale)
+            continue;
+        if (mode == 5 && (part & 1))
+            continue;                                          // (this loop's rate run faulted the GPU)
         // part 0: 8 waves x 2 chunks, checked; part 1: 7 waves per SIMD on 256 CUs x 16 chunks, timed
         const int nwaves = (part & 1) == 0 ? 8 : 256 * 4 * 7 * 2;
         const int nchunks = (part & 1) == 0 ? 2 : 16;
