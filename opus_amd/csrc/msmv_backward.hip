@@ -1282,6 +1282,15 @@ msmv_bwd_gather_c64(const MsmvArgs a, const OwnerWs ws)
             tap[l] = msmv_make_tap(lx, ly, H, W, view_ok);
             const float *base = a.lvl[l].feat + (slab * (size_t)(H * W)) * 64 + l16 * 4;
             // (finest level: streaming hint, as in the forward)
+#ifdef MSMV_ABL_SKIP_COARSE
+            // development aid (wrong results): levels 2.. cost no memory access at all - the bound on
+            // what serving them from an LDS-staged copy could save
+            if (l >= 2) {
+                const float c = __int_as_float(0x3f800000 + tap[l].o1 + tap[l].o4);
+                v[l][0] = v[l][1] = v[l][2] = v[l][3] = make_float4(c, c, c, c);
+                continue;
+            }
+#endif
             v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l < MSMV_STREAM_LEVELS);
             v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l < MSMV_STREAM_LEVELS);
             v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l < MSMV_STREAM_LEVELS);
@@ -1440,6 +1449,15 @@ msmv_fwd_sorted_c64(const MsmvArgs a, const OwnerWs ws)
         const int H = a.lvl[l].H, W = a.lvl[l].W;
         tap[l] = msmv_make_tap(lx, ly, H, W, view_ok);
         const float *base = a.lvl[l].feat + (slab * (size_t)(H * W)) * 64 + l16 * 4;
+#ifdef MSMV_ABL_SKIP_COARSE
+        // development aid (wrong results): levels 2.. cost no memory access at all - the bound on
+        // what serving them from an LDS-staged copy could save
+        if (l >= 2) {
+            const float c = __int_as_float(0x3f800000 + tap[l].o1 + tap[l].o4);
+            v[l][0] = v[l][1] = v[l][2] = v[l][3] = make_float4(c, c, c, c);
+            continue;
+        }
+#endif
         v[l][0] = ld4_level(base + (size_t)tap[l].o1 * 64, l < MSMV_STREAM_LEVELS);
         v[l][1] = ld4_level(base + (size_t)tap[l].o2 * 64, l < MSMV_STREAM_LEVELS);
         v[l][2] = ld4_level(base + (size_t)tap[l].o3 * 64, l < MSMV_STREAM_LEVELS);
@@ -1454,8 +1472,7 @@ msmv_fwd_sorted_c64(const MsmvArgs a, const OwnerWs ws)
         {                                                                          \
             const float v1 = t.c1 ? v[l][0].X : 0.f, v2 = t.c2 ? v[l][1].X : 0.f;  \
             const float v3 = t.c3 ? v[l][2].X : 0.f, v4 = t.c4 ? v[l][3].X : 0.f;  \
-            const float val = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;       \
-            acc.X = t.ok ? acc.X + val * wl[l] : acc.X;                            \
+            acc.X = msmv_accum_level(t, acc.X, msmv_blend4(t, v1, v2, v3, v4), wl[l]); \
         }
         MSMV_FWDS_CH(x) MSMV_FWDS_CH(y) MSMV_FWDS_CH(z) MSMV_FWDS_CH(w)
 #undef MSMV_FWDS_CH

@@ -142,6 +142,20 @@ __device__ __forceinline__ MsmvTap msmv_make_tap(float loc_w, float loc_h, int H
     return t;
 }
 
+// The bilinear blend and the accumulation over levels with ONE rounding order for every kernel that
+// promises bit-identical results (a sum of products leaves the compiler a choice of which product to
+// fuse into the multiply-add; written out, there is none).
+__device__ __forceinline__ float msmv_blend4(const MsmvTap &t, float v1, float v2, float v3, float v4)
+{
+    return fmaf(t.w4, v4, fmaf(t.w3, v3, fmaf(t.w2, v2, t.w1 * v1)));
+}
+
+__device__ __forceinline__ float msmv_accum_level(const MsmvTap &t, float acc, float val, float wl)
+{
+    // a level that is out of range adds nothing at all (msmv_sampling_forward.cu:126)
+    return t.ok ? fmaf(val, wl, acc) : acc;
+}
+
 // view index of a point: round-half-away-from-zero of loc_v*(N-1) (forward.cu:110).
 // Returns -1 for anything that does not land in [0, N-1] (NaN, infinities, out of range):
 // the reference would index out of bounds there; such a point contributes nothing here.

@@ -119,9 +119,9 @@ def test_training_step_workload_runs_on_one_gpu():
     """OPUS-M training-step shape on one rank: six layers x (2 forwards + 1 backward); the
     gradient all-reduce has no peer at N = 1 (its two-rank path runs under gloo in
     tests/test_dist_gloo.py)."""
-    r = run_bench("--workload", "train-M", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    r = run_bench("--workload", "train-M", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--event-steps", "3")
     assert r["config"]["points_per_step_per_gpu"] == 6 * 32 * 2400 * 2
-    assert r["kernels"]["msmv_fwd_c64"]["launches"] == 12       # 6 layers x 2 forwards in the evented step
+    assert r["kernels"]["msmv_fwd_c64"]["launches"] == 3 * 12   # 6 layers x 2 forwards in each evented step
     assert r["value"] > 0
 
 
@@ -131,9 +131,12 @@ def test_rccl_calls_of_the_multi_rank_path_in_a_group_of_one():
     the MAX reduction of the elapsed time, train-M's bucketed all-reduce on a side stream - through
     RCCL itself, in a group of one rank (this box has one GPU; RCCL refuses two ranks on one device)."""
     r = run_bench("--gpus", "1", "--init-group", "--workload", "train-M", "--steps", "2", "--warmup", "1",
-                  "--settle-ms", "20", "--no-cpu-baseline", timeout=200)
+                  "--settle-ms", "20", "--no-cpu-baseline", "--event-steps", "2", timeout=200)
     assert r["n_gpus"] == 1 and r["config"]["backend"] == "nccl"
     assert r["config"]["allreduce_bytes_per_step"] == 300 * 1000 * 1000
+    # two buckets handed to RCCL after each layer's backward, one join at the end of the step
+    assert r["config"]["allreduce_schedule"] == [[layer, 2 * layer + k] for layer in range(6) for k in range(2)]
+    assert r["allreduce_exposed_us"] is not None
     assert r["value"] > 0
 
 
