@@ -550,6 +550,12 @@ def main():
     rank, world, local_rank = odist.env_rank()
     if world != args.gpus:
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    # stdout carries ONE line, the result.  Native libraries write there too (RCCL prints a version
+    # banner when its first communicator is made): from here on file descriptor 1 is stderr, and the
+    # result line goes to the descriptor saved here.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     stub = args.stub_compute
     if stub:
         device = torch.device("cpu")
@@ -835,7 +841,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not stub:
             result["cpu_baseline"] = cpu_baseline(variant, do_bwd)
-        print(json.dumps(result), flush=True)
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

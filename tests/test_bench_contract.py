@@ -18,6 +18,8 @@ def run_bench(*args, timeout=300):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    # ... and nothing else on stdout (native libraries' banners go to stderr)
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == lines, p.stdout[:2000]
     return json.loads(lines[0])
 
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the bench.py lines committed under profiles/ (copied from gpurun_out/<tag>/).
-#   gpurun -- 'bash tools/collect_bench.sh r02'
+#   gpurun -- 'bash tools/collect_bench.sh r03'
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG/bench
 mkdir -p "$O"
@@ -32,5 +32,13 @@ run sampling4d-T --workload sampling4d-T --no-cpu-baseline
 run L_graph --graph --no-cpu-baseline
 run decoder-L_graph --workload decoder-L --graph --steps 100 --no-cpu-baseline
 run decoder-L_cameras --workload decoder-L --points cameras --steps 100 --no-cpu-baseline
+run L_queries --points queries --no-cpu-baseline                   # the decoder's query-clustered points
+run decoder-L_queries --workload decoder-L --points queries --steps 100 --no-cpu-baseline
+run chain-L --workload chain-L --steps 100 --no-cpu-baseline       # the whole sampling chain of a training step
+run chain-L_queries --workload chain-L --points queries --steps 100 --no-cpu-baseline
+run chain-T --workload chain-T --steps 100 --no-cpu-baseline
+run infer-L --workload infer-L --steps 200 --no-cpu-baseline       # ... and of an inference frame
+run infer-L_queries --workload infer-L --points queries --steps 200 --no-cpu-baseline
+run train-M_group --workload train-M --steps 50 --init-group --no-cpu-baseline   # RCCL in a group of one: schedule + exposed time
 timeout -k 10 200 python3 tools/bench_sampling4d.py > "$O/${TAG}_sampling4d_fusion.json" 2> "$O/fusion.err" || exit 1
 echo "bench lines under $O"

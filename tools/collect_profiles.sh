@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel stats of bench.py plus the HBM-traffic
 # PMC passes (each in a run of its own), written under gpurun_out/<tag>/.
-#   gpurun -- 'bash tools/collect_profiles.sh r02 [bench.py arguments, e.g. --workload sampling4d-L]'
+#   gpurun -- 'bash tools/collect_profiles.sh r03 [bench.py arguments, e.g. --workload sampling4d-L]'
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -18,4 +18,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_su
 done
 timeout -k 10 60 "$R/tools/calib_fetch" > "$O/calib.txt" 2>&1 || true
 timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/calib_fetch" -- "$R/tools/calib_fetch" > /dev/null 2>&1 || true
+# keep what the summaries are made of (kernel stats, mean counter values): the raw files are large
+find "$O" -name "*kernel_trace.csv" -delete -o -name "*domain_stats.csv" -delete
+python3 "$R/tools/pmc_reduce.py" "$O"
 echo "profiles collected under $O"

@@ -27,7 +27,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 workload = sys.argv[2] if len(sys.argv) > 2 else "L-fwdbwd"
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 points = sys.argv[4] if len(sys.argv) > 4 else "uniform"
-out_tag = tag if workload == "L-fwdbwd" else f"{tag}_{workload}"
+out_tag = f"{tag}_{workload}"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
@@ -36,7 +36,8 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     for k in ("msmv_fwd_c64", "msmv_fwd_sorted_c64", "msmv_bwd_owner_dfeat", "msmv_bwd_gather_c64", "msmv_bin_count",
-              "msmv_bin_fill", "msmv_bin_one", "msmv_bwd_atomic", "msmv_fwd_generic", "msmv_project_pack", "calib_gather"):
+              "msmv_bin_fill", "msmv_bin_one", "msmv_bwd_atomic", "msmv_fwd_generic", "msmv_project_pack_fwd",
+              "msmv_project_pack_bwd", "msmv_relayout", "calib_gather"):
         if k in name:
             return k
     return None
@@ -74,7 +75,7 @@ for k, cs in summary.items():
         cs["l2_hit_rate"] = cs["TCC_HIT_sum"] / (cs["TCC_HIT_sum"] + cs["TCC_MISS_sum"])
     # the bench's record of a kernel: bytes per launch, the kernel instance they were measured on
     # (bench.py's name of the kernel in this workload)
-    bench_name = {"msmv_fwd_sorted_c64": "msmv_fwd_sorted"}.get(k, k)
+    bench_name = {"msmv_fwd_sorted_c64": "msmv_fwd_sorted", "msmv_project_pack_fwd": "msmv_project_pack"}.get(k, k)
     if k == "msmv_bwd_owner_dfeat" and (workload.startswith("decoder-") or workload == "train-M" or workload.startswith("chain-")):
         bench_name = "msmv_bwd_owner_dfeat(6 layers)"
     traffic[bench_name] = {

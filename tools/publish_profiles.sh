@@ -1,16 +1,19 @@
 #!/bin/bash
-# Runs in the build container after `gpurun -- 'bash tools/collect_bench.sh r02; bash tools/collect_profiles.sh
-# r02p; ... r02_s4d --workload sampling4d-L; ... r02_T --workload T-fwdbwd'`: turns what came back under
-# gpurun_out/ into the committed files under profiles/.
+# Runs in the build container after
+#   gpurun -- 'bash tools/collect_bench.sh r03 && bash tools/collect_profiles.sh r03_L &&
+#              for w in T-fwdbwd sampling4d-L decoder-L train-M chain-L; do bash tools/collect_profiles.sh r03_$w --workload $w || exit 1; done'
+# turns what came back under gpurun_out/ into the committed files under profiles/ (kernel stats, PMC
+# summaries, traffic.json keyed by workload | batch | points and stamped with the kernel sources' hash).
 set -e
 cd "$(dirname "$0")/.."
-rm -rf gpurun_out/r02/stats gpurun_out/r02/pmc_* gpurun_out/r02/calib*
-cp -r gpurun_out/r02p/* gpurun_out/r02/ && rm -rf gpurun_out/r02p
-python tools/make_profile_summary.py r02 L-fwdbwd 1 uniform > /dev/null
-python tools/make_profile_summary.py r02_s4d sampling4d-L 1 uniform > /dev/null
-python tools/make_profile_summary.py r02_T T-fwdbwd 1 uniform > /dev/null
-cd profiles
-for f in r02_s4d_sampling4d-L_*; do mv -f "$f" "${f/r02_s4d_sampling4d-L/r02_sampling4d-L}"; done
-for f in r02_T_T-fwdbwd_*; do mv -f "$f" "${f/r02_T_T-fwdbwd/r02_T-fwdbwd}"; done
-cd ..
-cp gpurun_out/r02/bench/r02_*.json profiles/
+TAG=${1:-r03}
+python tools/make_profile_summary.py ${TAG}_L L-fwdbwd 1 uniform > /dev/null
+cd profiles; for f in ${TAG}_L_L-fwdbwd_*; do [ -e "$f" ] && mv -f "$f" "${f/${TAG}_L_L-fwdbwd/${TAG}_L-fwdbwd}"; done; cd ..
+sed -i "s#profiles/${TAG}_L_L-fwdbwd_pmc.json#profiles/${TAG}_L-fwdbwd_pmc.json#" profiles/traffic.json
+for w in T-fwdbwd sampling4d-L decoder-L train-M chain-L; do
+    pts=uniform; [ $w = chain-L ] && pts=cameras
+    python tools/make_profile_summary.py ${TAG}_$w $w 1 $pts > /dev/null
+    cd profiles; for f in ${TAG}_${w}_${w}_*; do [ -e "$f" ] && mv -f "$f" "${f/${TAG}_${w}_${w}/${TAG}_${w}}"; done; cd ..
+    sed -i "s#profiles/${TAG}_${w}_${w}_pmc.json#profiles/${TAG}_${w}_pmc.json#" profiles/traffic.json
+done
+cp gpurun_out/${TAG}/bench/${TAG}_*.json profiles/
