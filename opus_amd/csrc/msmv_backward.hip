@@ -494,7 +494,7 @@ constexpr int OWN_THREADS = OWN_WAVES * 64;
 #define MSMV_OWN_SPLIT_HITS 64                   // expected hits per wave above which a level's patches are shared
 #endif
 #ifndef MSMV_OWN_SPLIT_HITS_MULTI
-#define MSMV_OWN_SPLIT_HITS_MULTI 256            // the same for a pass over several point sets: per-patch set-up is spread over
+#define MSMV_OWN_SPLIT_HITS_MULTI 128            // the same for a pass over several point sets: per-patch set-up is spread over
 #endif                                           // more hits there (six OPUS-L layers: 64 -> 795 us, 256 -> 764, 1024 -> 768 but 1017 on crowded images)
 constexpr int OWN_QCAP = 16;             // hit records a wave queues before consuming them
 
