@@ -230,7 +230,8 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
     """Raw backward into caller-owned buffers (no allocation here when ``workspace`` is
     given).  ``flags``: algorithm | ACCUMULATE | STAGE_* bits of include/opus_msmv.h.
     ``rows=(T, G)``: grad_out is [Bs, Q, G, T*P, C] (see msmv_forward).  ``dfeats`` may be None
-    when the stages asked for do not include the d-feat pass."""
+    when the stages asked for do not include the d-feat pass, ``dloc`` / ``dw`` when they do not
+    include the gather."""
     L, B, C, N, Q, P, hw = _check_inputs(feats, loc, w)
     if rows is None:
         want = (B, Q, C, P)
@@ -243,7 +244,10 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
     for d, f in zip(dfeats or [], feats):
         if d.shape != f.shape or not d.is_contiguous() or d.dtype != torch.float32 or d.device != f.device:
             raise RuntimeError("d feats must match feats in shape, dtype and device and be contiguous")
-    if dloc.shape != loc.shape or dw.shape != w.shape or not dloc.is_contiguous() or not dw.is_contiguous():
+    if (dloc is None) != (dw is None):
+        raise RuntimeError("dloc and dweights are given or left out together")
+    if dloc is not None and (dloc.shape != loc.shape or dw.shape != w.shape or not dloc.is_contiguous()
+                             or not dw.is_contiguous()):
         raise RuntimeError("dloc / dweights must match sampling_loc / attn_weight and be contiguous")
     lib = _lib.load()
     with torch.cuda.device(loc.device):
@@ -253,7 +257,7 @@ def msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=None
         head = (L, grad_out.data_ptr(), _lib.ptr_array([f.data_ptr() for f in feats]),
                 _lib.int_array(hw), loc.data_ptr(), w.data_ptr())
         tail = (_lib.ptr_array([d.data_ptr() for d in dfeats]) if dfeats is not None else None,
-                dloc.data_ptr(), dw.data_ptr(),
+                dloc.data_ptr() if dloc is not None else None, dw.data_ptr() if dw is not None else None,
                 workspace.data_ptr(), workspace.numel() * workspace.element_size(), flags,
                 _stream_ptr(loc.device))
         if rows is None:
@@ -294,22 +298,50 @@ def msmv_dfeat_multi(grad_outs, workspaces, feats, Q, P, dfeats, rows=None, accu
     _lib.check(rc, "opus_msmv_dfeat_multi")
 
 
-def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None, out_dfeats=None, sorted_ws=None):
+def msmv_backward(grad_out, feats, loc, w, algo=None, dfeats=None, rows=None, out_dfeats=None, sorted_ws=None,
+                  need=(True, True)):
     """Raw backward -> (dfeats list, dloc, dw).  ``dfeats`` given => accumulate into them;
     ``out_dfeats`` given => overwrite those buffers instead of allocating new ones; ``sorted_ws``:
-    the workspace msmv_forward_sorted left for these loc / weights (owner algorithm, sort skipped)."""
-    flags = _BWD_ALGOS[_bwd_algo if algo is None else algo]
+    the workspace msmv_forward_sorted left for these loc / weights (owner algorithm, sort skipped).
+
+    ``need = (d feats wanted, d loc / d weights wanted)``: the owner algorithm computes the two groups
+    in separate passes (d-feat pass, gather), so a group nobody asked for - frozen feature maps, or
+    locations and weights that are constants - is not computed and comes back as None(s).  The
+    reference always computes all three (msmv_sampling.cpp:212-281)."""
+    need_dfeat, need_dlw = bool(need[0]), bool(need[1])
+    if not (need_dfeat or need_dlw):
+        return [None] * len(feats), None, None
+    name = _bwd_algo if algo is None else algo
+    flags = _BWD_ALGOS[name]
     if sorted_ws is not None:
         flags = _lib.BWD_OWNER | _lib.BWD_PRESORTED
-    if dfeats is None:
-        dfeats = out_dfeats if out_dfeats is not None else [torch.empty_like(f) for f in feats]
+    accumulate = dfeats is not None
+    if sorted_ws is not None and (grad_out.data_ptr() % 16 or any(d.data_ptr() % 16 for d in (dfeats or out_dfeats or []))):
+        sorted_ws, flags = None, _BWD_ALGOS[name]
+    if not (need_dfeat and need_dlw):
+        # one group only: possible where the owner algorithm takes the tensors (its passes are stages)
+        staged = sorted_ws is not None or (
+            name != "atomic" and _aligned16(grad_out, *feats, *(dfeats or out_dfeats or []))
+            and backward_workspace_bytes(feats, loc, w, _lib.BWD_OWNER) > 0)
+        if staged:
+            flags = _lib.BWD_OWNER | (_lib.BWD_PRESORTED if sorted_ws is not None else _lib.BWD_STAGE_BIN)
+            flags |= _lib.BWD_STAGE_DFEAT if need_dfeat else _lib.BWD_STAGE_GATHER
+    if need_dfeat or not (flags & _lib.BWD_STAGE_GATHER):
+        if dfeats is None:
+            dfeats = out_dfeats if out_dfeats is not None else [torch.empty_like(f) for f in feats]
     else:
+        dfeats = None
+    if accumulate:
         flags |= _lib.BWD_ACCUMULATE
-    dloc = torch.empty_like(loc)
-    dw = torch.empty_like(w)
-    if sorted_ws is not None and (grad_out.data_ptr() % 16 or any(d.data_ptr() % 16 for d in dfeats)):
-        sorted_ws, flags = None, (flags & _lib.BWD_ACCUMULATE) | _BWD_ALGOS[_bwd_algo if algo is None else algo]
+    dloc = dw = None
+    if need_dlw or not (flags & _lib.BWD_STAGE_DFEAT):
+        dloc = torch.empty_like(loc)
+        dw = torch.empty_like(w)
     msmv_backward_into(grad_out, feats, loc, w, dfeats, dloc, dw, workspace=sorted_ws, flags=flags, rows=rows)
+    if not need_dfeat:
+        dfeats = [None] * len(feats)
+    if not need_dlw:
+        dloc = dw = None
     return dfeats, dloc, dw
 
 
@@ -333,8 +365,10 @@ class _MSMVSampling(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         *feats, sampling_locations, scale_weights = ctx.saved_tensors
+        n = len(feats)
+        need = (any(ctx.needs_input_grad[:n]), any(ctx.needs_input_grad[n:n + 2]))
         dfeats, dloc, dw = msmv_backward(grad_output.contiguous(), feats,
-                                         sampling_locations, scale_weights, sorted_ws=ctx.sorted_ws)
+                                         sampling_locations, scale_weights, sorted_ws=ctx.sorted_ws, need=need)
         return (*dfeats, dloc, dw)
 
 
@@ -373,9 +407,11 @@ class MSMVSamplingRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         *feats, sampling_locations, scale_weights = ctx.saved_tensors
+        n = len(feats)
+        need = (any(ctx.needs_input_grad[2:2 + n]), any(ctx.needs_input_grad[2 + n:4 + n]))
         dfeats, dloc, dw = msmv_backward(grad_output.contiguous(), feats,
                                          sampling_locations, scale_weights, rows=ctx.rows,
-                                         sorted_ws=ctx.sorted_ws)
+                                         sorted_ws=ctx.sorted_ws, need=need)
         return (None, None, *dfeats, dloc, dw)
 
 

@@ -351,6 +351,68 @@ def test_autograd_functions_and_dispatch(wr, oracle):
         wr.MSMVSamplingC23456.apply(*[x.detach() for x in f], l.detach(), ww.detach())
 
 
+@pytest.mark.parametrize("algo", ["auto", "atomic"])
+@pytest.mark.parametrize("which", ["feats", "points", "weights only"])
+def test_backward_computes_only_the_gradient_groups_asked_for(wr, oracle, which, algo):
+    """Frozen feature maps (or constant locations / weights): autograd asks for one group of
+    gradients only; the other group's pass is skipped where the owner algorithm applies (P = 1: on
+    the sort the bin-ordered forward left; P = 2: on a sort of its own; C = 8: the atomic
+    algorithm computes everything and the unwanted part is dropped).  The wanted gradients are the
+    oracle's either way."""
+    from opus_amd import opus_sampling  # noqa: F401  (the rows Function below lives in the wrapper)
+    wr.set_backward_algo(algo)
+    try:
+        for levels, C, P in ((REAL_LEVELS, 64, 1), (REAL_LEVELS, 64, 2), (TINY_LEVELS, 8, 3)):
+            feats, loc, w, grad_out = random_case(77 + P, levels, B=2, N=6, C=C, Q=23, P=P)
+            ref_df, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
+            f = [dev(x).requires_grad_(which == "feats") for x in feats]
+            l = dev(loc).requires_grad_(which == "points")
+            ww = dev(w).requires_grad_(which in ("points", "weights only"))
+            out = wr.msmv_sampling(f, l, ww)
+            out.backward(dev(grad_out))
+            torch.cuda.synchronize()
+            if which == "feats":
+                for i in range(4):
+                    assert_close(f[i].grad.cpu().numpy(), ref_df[i], GRAD_RTOL, f"dfeat{i} alone, P={P}")
+                assert l.grad is None and ww.grad is None
+            else:
+                assert all(x.grad is None for x in f)
+                assert_close(ww.grad.cpu().numpy(), ref_dw, GRAD_RTOL, f"dw without d feats, P={P}")
+                if which == "points":
+                    assert_close(l.grad.cpu().numpy(), ref_dloc, GRAD_RTOL, f"dloc without d feats, P={P}")
+                else:
+                    assert l.grad is None
+        # the raw form says what was computed: a group that was not asked for comes back as None
+        feats, loc, w, grad_out = random_case(5, REAL_LEVELS, B=1, N=6, C=64, Q=9, P=2)
+        f, l, ww, g = [dev(x) for x in feats], dev(loc), dev(w), dev(grad_out)
+        df, dl, dww = wr.msmv_backward(g, f, l, ww, need=(False, True))
+        assert df == [None] * 4 and dl is not None and dww is not None
+        df, dl, dww = wr.msmv_backward(g, f, l, ww, need=(True, False))
+        assert dl is None and dww is None
+        ref_df, _, _ = oracle.backward(grad_out, feats, loc, w)
+        for i in range(4):
+            assert_close(df[i].cpu().numpy(), ref_df[i], GRAD_RTOL, f"dfeat{i}, raw form")
+        assert wr.msmv_backward(g, f, l, ww, need=(False, False)) == ([None] * 4, None, None)
+    finally:
+        wr.set_backward_algo("auto")
+
+
+def test_rows_function_with_frozen_feature_maps(wr, oracle):
+    """The caller-layout Function with feature maps that need no gradient: sort + gather only."""
+    T, G, Bs, Q, P = 2, 2, 1, 17, 2
+    feats, loc, w, grad_out = random_case(31, REAL_LEVELS, B=Bs * T * G, N=6, C=64, Q=Q, P=P)
+    _, ref_dloc, ref_dw = oracle.backward(grad_out, feats, loc, w)
+    f = [dev(x) for x in feats]
+    l, ww = dev(loc).requires_grad_(True), dev(w).requires_grad_(True)
+    out = wr.msmv_sampling_rows(f, l, ww, T, G)
+    # grad_out [B', Q, C, P] -> the caller's [Bs, Q, G, T*P, C] (models/opus_sampling.py:119-122)
+    g_rows = dev(grad_out).reshape(Bs, T, G, Q, 64, P).permute(0, 3, 2, 1, 5, 4).reshape(Bs, Q, G, T * P, 64)
+    out.backward(g_rows.contiguous())
+    torch.cuda.synchronize()
+    assert_close(l.grad.cpu().numpy(), ref_dloc, GRAD_RTOL, "dloc, frozen feature maps")
+    assert_close(ww.grad.cpu().numpy(), ref_dw, GRAD_RTOL, "dw, frozen feature maps")
+
+
 def test_precondition_errors(wr):
     feats, loc, w, _ = random_case(3, TINY_LEVELS, B=1, N=6, C=8, Q=4, P=2)
     f = [dev(x) for x in feats]

@@ -20,8 +20,7 @@ Q, P = VARIANTS[variant]
 feats, loc, w, g = make_inputs(32, Q, P)
 if os.environ.get("POINTS") == "cameras":
     import numpy as np
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
-    from procedural import synthetic_occ2img
+    from tools.synthetic_cameras import synthetic_occ2img
     from opus_amd import opus_sampling
     gen = torch.Generator(device="cuda").manual_seed(1)
     lo, hi = torch.tensor([-40.0, -40.0, -1.0], device="cuda"), torch.tensor([40.0, 40.0, 5.4], device="cuda")
