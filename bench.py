@@ -86,6 +86,11 @@ def parse_args(argv=None):
                     help="caller-layout workloads (sampling4d-*): 'bin' sorts the points once per layer and runs "
                          "the forward in bin order, the backward re-using the sort; 'input': forward in input "
                          "order, the backward sorts for itself (default: bin, input for infer-*)")
+    ap.add_argument("--no-checkpoint", action="store_true",
+                    help="chain-* workloads: one forward per layer instead of two - the decoder without the "
+                         "activation checkpointing of its sampling module (models/opus_transformer.py:372-378), "
+                         "which trades a second forward for 79 MB of sampled features per layer and sample at "
+                         "OPUS-L; with 288 GB of HBM per GPU the memory is there")
     ap.add_argument("--split-sample", action="store_true",
                     help="single-sample latency mode: the 32*batch slabs are split across the ranks (strong "
                          "scaling, still no data-path collective) instead of one whole batch per rank")
@@ -580,7 +585,7 @@ def main():
         # the decoder's sampling chain (models/opus_transformer.py:113-136, 372-378): re-layout once,
         # six layers; in training every layer's forward runs twice (activation checkpointing)
         variant, do_bwd, n_layers = wl.split("-")[1], wl.startswith("chain-"), 6
-        n_fwd = 2 if do_bwd else 1
+        n_fwd = 2 if do_bwd and not args.no_checkpoint else 1
         assert variant in VARIANTS, wl
     elif wl.startswith("decoder-"):
         variant, do_bwd, n_layers = wl.split("-")[1], True, 6
@@ -797,7 +802,7 @@ def main():
                                    f"{'forward + backward' if do_bwd else 'forward'}"
                                    f"{', %d decoder layers' % n_layers if n_layers > 1 else ''}"
                                    f"{', 2 forwards per backward + gradient all-reduce' if wl == 'train-M' else ''}"
-                                   f"{', with the feature re-layout' + (', 2 forwards per backward (activation checkpointing), d feats back in the backbone layout' if do_bwd else '') if chain else ''}",
+                                   f"{', with the feature re-layout' + ((', 2 forwards per backward (activation checkpointing)' if n_fwd == 2 else ', no activation checkpointing') + ', d feats back in the backbone layout' if do_bwd else '') if chain else ''}",
                        "name": wl, "Q": Q, "P": P, "slabs_per_gpu": Bp, "views": N_VIEWS,
                        "levels": LEVELS, "channels": CHANNELS, "batch_per_gpu": args.batch,
                        "points_per_step_per_gpu": npts_step, "bwd_algo": args.bwd_algo if do_bwd else None,
