@@ -557,7 +557,7 @@ typedef __attribute__((address_space(3))) void *msmv_lptr_t;
 #define MSMV_OWN_STAGE_F4 256                    // 4 KiB per wave: with the queue, LDS never limits the occupancy
 #endif
 #ifndef MSMV_OWN_OCC
-#define MSMV_OWN_OCC (MULTI || ACC ? 4 : 7), 8  // the plain single-set kernel fits 7 waves per SIMD (72 VGPRs)
+#define MSMV_OWN_OCC (MULTI || ACC || HL != 0 ? 4 : 7), 8  // the plain single-set kernel fits 7 waves per SIMD (72 VGPRs)
 #endif
 
 // d feat is written once and not read again by this pass: a streaming (non-temporal) store
@@ -674,10 +674,28 @@ __device__ unsigned long long *msmv_dbg_buf;
 #define MSMV_DBG_HSTAMP(K)
 #endif
 
-template <int PT, bool ACC, bool MULTI>
+// H16: the hit loop on 16 x 16 x 4 matrix tiles (v_mfma_f32_16x16x4_f32, 32 matrix-pipe cycles for
+// four hits x 16 pixels x 16 channels) instead of 32 x 32 x 2 ones.  The patch is worked on as two
+// HALVES of 4 x 4 pixels (columns 0..3 / 4..7): a hit is queued for the half - or the two halves - its
+// footprint reaches (10 / 9 halves per hit), and a group of four queued hits costs four matrix
+// instructions, one per tile of 16 channel quadruples: 35 matrix-pipe cycles per hit instead of 64.
+// Lane (n, k) = (lane % 16, lane / 16) supplies for hit k of a group the weight of half-pixel n
+// (A operand) and channels 4n .. 4n+3 of the hit's gradient row (B operands of the four tiles: tile
+// t holds channel 4n + t in column n) - 16 contiguous bytes, loaded straight into registers, the
+// row's 256 bytes by 16 neighbouring lanes, no staging in LDS.  Accumulator register i of tile t
+// in lane (n, r) is pixel (row r, column i) of the half, channel 4n + t: the four tiles' registers
+// i form 16 contiguous bytes of d feat, and one store instruction writes a column of the half -
+// 4 rows x 256 contiguous bytes.  Row mode / P <= 2, no ACC.
+// HL (hit loop): 0 = 32 x 32 x 2 tiles over whole patches; 1 = 16 x 16 x 4 tiles over half patches, the
+// rows of two groups of four hits requested together, then both groups applied; 2 = the same tiles, one
+// group at a time with the next group's rows requested before this group is applied.
+template <int PT, bool ACC, bool MULTI, int HL = 0>
 __global__ void __launch_bounds__(OWN_THREADS) __attribute__((amdgpu_waves_per_eu(MSMV_OWN_OCC)))
 msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
 {
+    constexpr bool H16 = HL != 0;
+    static_assert(HL >= 0 && HL <= 2, "hit loop kind");
+    static_assert(!H16 || ((PT == 1 || PT == 2) && !ACC), "the 16 x 16 x 4 hit loop: contiguous gradient rows, plain stores");
 #ifdef MSMV_DBG_TIMES
     unsigned long long dbg_t[6] = {};
     dbg_t[0] = __builtin_amdgcn_s_memrealtime();
@@ -771,7 +789,9 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
     const int nrow = min(PATCH_H, H - r0), ncol = min(PATCH_W, W - c0);
     MSMV_DBG_HSTAMP(2)
 
-    msmv_f32x16 acc0 = {}, acc1 = {};                        // channels 0..31 / 32..63
+    [[maybe_unused]] msmv_f32x16 acc0 = {}, acc1 = {};       // channels 0..31 / 32..63
+    typedef float msmv_f32x4v __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] msmv_f32x4v hacc[2][4] = {};            // H16: [half][tile]
     [[maybe_unused]] bool any_hit = false;
     [[maybe_unused]] bool touched = false;                   // ACC: pixel l32 of this half's records got a weight
 
@@ -907,170 +927,311 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         for (int j0 = 0; (j0 << klog) + sub < total; j0 += 64) {
             const OwnHit h = scan(j0, e0, wl);
             [[maybe_unused]] const float hset = __int_as_float(eset);
+            [[maybe_unused]] const int eset_of_h = eset;
             if (((j0 + 64) << klog) + sub < total)             // next chunk's entries, in flight
                 load_entry(entry_index(j0 + 64), e0, wl, eset);     // while this chunk's hits are applied
 
-            unsigned long long hits = __ballot(h.hit);
+            if constexpr (H16) {
+                const int hn = lane & 15, hk = lane >> 4;    // half-pixel / channel quadruple; hit within a group of four
+                // Columns 4 hf .. 4 hf + 3 of the patch are reached by a footprint that begins at column
+                // 4 hf - 1 .. 4 hf + 3 (one on columns 3 and 4 is queued for both halves).  The chunk's
+                // records: those of the left half first, padded to whole groups of four, then the right
+                // half's, padded likewise - a group belongs to one half, whose tiles its matrix
+                // instructions name.  A record is HREC_DW dwords: the gradient row's address, then the
+                // separable weight tables for rows -1 .. 4 and the half's columns -1 .. 4.
+                constexpr int HREC_DW = 16, HREC_Y0 = 3, HREC_X0 = 9;
+                constexpr int GPB = HL == 2 ? 1 : 2;                   // groups of four records per batch of row loads
+                constexpr int HPAD = HL == 2 ? 4 * GPB : 4;            // a half's records are padded to a multiple of this
+                constexpr int HQ = STAGE_F4 * 4 / HREC_DW;             // records the wave's queue holds (its staging area)
+                static_assert(HQ >= 64 && HQ % HPAD == 0, "a chunk's records of one half fit the queue");
+                float *hqueue = reinterpret_cast<float *>(stage);
+                const bool inL = h.hit && h.dc0 <= 3, inR = h.hit && h.dc0 >= 3;
+                unsigned long long hitsL = __ballot(inL), hitsR = __ballot(inR);
 #ifdef MSMV_ABL_NOHITS
-            asm volatile("" ::"v"(h.dr0), "v"(h.dc0), "v"(h.y0), "v"(h.y1), "v"(h.x0), "v"(h.x1));
-            hits = 0;
+                asm volatile("" ::"v"(h.dr0), "v"(h.dc0), "v"(h.y0), "v"(h.y1), "v"(h.x0), "v"(h.x1));
+                hitsL = hitsR = 0;
 #endif
-            const int nh = __popcll(hits);
-            if constexpr (ACC)
-                any_hit = any_hit || nh > 0;
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
-            for (int qbase = 0; qbase < nh; qbase += QC) {
-                // every slot first becomes a null record (a valid point, all weights 0), then
-                // hit lanes qbase .. qbase+QC-1 (in lane order) fill theirs in: the queue can
-                // then be consumed in whole pairs without branches around the loads
-                if (lane < QC) {
+                const int nL = __popcll(hitsL), nR = __popcll(hitsR);
+                const int padL = (nL + HPAD - 1) / HPAD * HPAD, padR = (nR + HPAD - 1) / HPAD * HPAD;
+                const int slotL = __builtin_amdgcn_mbcnt_hi((unsigned)(hitsL >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hitsL, 0u));
+                const int slotR = __builtin_amdgcn_mbcnt_hi((unsigned)(hitsR >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hitsR, 0u));
+                // what a record says about its gradient row: the address of the row's first float (P = 2: of
+                // the query's [channel][point] pairs, the point in bit 2 - rows are 16-byte aligned)
+                const float *hrow = gout;
+                if constexpr (MULTI)
+                    hrow = gout_tab[eset_of_h];
+                hrow += (size_t)(PT == 2 ? h.pt >> 1 : h.pt) * (PT * 64);
+                const unsigned long long hrow_bits = reinterpret_cast<unsigned long long>(hrow) | (PT == 2 ? (unsigned long long)(h.pt & 1) << 2 : 0ull);
+                const float hrow_lo = __int_as_float((int)(unsigned)hrow_bits), hrow_hi = __int_as_float((int)(unsigned)(hrow_bits >> 32));
+
+                // one half's records -> the queue -> the half's tiles (hf is a constant: the tiles are registers)
+                auto half_pass = [&](auto hfc, bool mine, int slot, int n_pad, int dch) {
+                    constexpr int hf = decltype(hfc)::value;
+                    if (n_pad == 0)
+                        return;                                        // wave-uniform
+                    // null records first (a valid row, all weights 0), then the hit lanes' own: whole
+                    // groups of four are then loaded and applied without per-record tests
                     typedef float rec_f32x4 __attribute__((ext_vector_type(4)));
-                    rec_f32x4 *rec = reinterpret_cast<rec_f32x4 *>(queue4 + lane * (REC_DW / 4));
-                    const rec_f32x4 head = {__int_as_float(h.pt), MULTI ? hset : 0.f, 0.f, 0.f};
-                    const rec_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    rec[0] = head;
+                    if (lane < n_pad) {
+                        rec_f32x4 *rec = reinterpret_cast<rec_f32x4 *>(hqueue + lane * HREC_DW);
+                        const rec_f32x4 head = {hrow_lo, hrow_hi, 0.f, 0.f};
+                        const rec_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        rec[0] = head;
 #pragma unroll
-                    for (int i = 1; i < REC_DW / 4; ++i)
-                        rec[i] = zero;
-                }
-                const unsigned slot = (unsigned)(rank - qbase);
-                if (h.hit && slot < (unsigned)QC) {
-                    float *rec = queue + slot * REC_DW;
-                    rec[0] = __int_as_float(h.pt);
-                    rec[1] = MULTI ? hset : 0.f;
-                    rec[REC_Y0 + h.dr0] = h.y0;
-                    rec[REC_Y0 + 1 + h.dr0] = h.y1;
-                    rec[REC_X0 + h.dc0] = h.x0;
-                    rec[REC_X0 + 1 + h.dc0] = h.x1;
-                }
-                const int cnt = min(QC, nh - qbase);
-                [[maybe_unused]] const int npairs = (cnt + 1) >> 1;
+                        for (int i = 1; i < HREC_DW / 4; ++i)
+                            rec[i] = zero;
+                    }
+                    if (mine) {
+                        float *rec = hqueue + slot * HREC_DW;
+                        rec[0] = hrow_lo;
+                        rec[1] = hrow_hi;
+                        rec[HREC_Y0 + h.dr0] = h.y0;
+                        rec[HREC_Y0 + 1 + h.dr0] = h.y1;
+                        rec[HREC_X0 + dch] = h.x0;
+                        rec[HREC_X0 + 1 + dch] = h.x1;
+                    }
+                    // A batch = GPB groups of four records: every record's row address first (one LDS read
+                    // each, all in flight together), then the batch's row loads - plain loads, the compiler
+                    // counts those in flight - then its matrix instructions.
+                    struct Batch {
+                        msmv_f32x4v g[GPB][PT];
+                        int odd[GPB];
+                    };
+                    auto load_batch = [&](auto ngc, int g0) {
+                        constexpr int NG = decltype(ngc)::value;
+                        Batch bt;
+                        const float *q0 = hqueue + (g0 * 4 + hk) * HREC_DW;
+                        unsigned long long rbits[NG];
+#pragma unroll
+                        for (int gi = 0; gi < NG; ++gi)
+                            rbits[gi] = *reinterpret_cast<const unsigned long long *>(q0 + gi * 4 * HREC_DW);
+#pragma unroll
+                        for (int gi = 0; gi < NG; ++gi) {
+                            typedef __attribute__((address_space(1))) const msmv_f32x4v *grow_t;
+                            const grow_t src = (grow_t)(rbits[gi] & ~15ull) + hn * PT;
+#pragma unroll
+                            for (int j = 0; j < PT; ++j)
+                                bt.g[gi][j] = src[j];
+                            bt.odd[gi] = (int)(rbits[gi] & 4ull);
+                        }
+                        return bt;
+                    };
+                    auto apply_batch = [&](auto ngc, const Batch &bt, int g0) {
+                        constexpr int NG = decltype(ngc)::value;
+                        const float *q0 = hqueue + (g0 * 4 + hk) * HREC_DW;
+                        float wa[NG];
+#pragma unroll
+                        for (int gi = 0; gi < NG; ++gi) {
+                            const float *r = q0 + gi * 4 * HREC_DW;
+                            wa[gi] = r[HREC_Y0 + (hn >> 2)] * r[HREC_X0 + (hn & 3)];
+                        }
+#pragma unroll
+                        for (int gi = 0; gi < NG; ++gi) {
+                            msmv_f32x4v b = bt.g[gi][0];
+                            if constexpr (PT == 2) {
+                                // [channel][point] pairs: the record's point picks the even or the odd floats
+                                const msmv_f32x4v lo = bt.g[gi][0], hi = bt.g[gi][PT - 1];
+                                const bool odd = bt.odd[gi] != 0;
+                                b = msmv_f32x4v{odd ? lo[1] : lo[0], odd ? lo[3] : lo[2], odd ? hi[1] : hi[0], odd ? hi[3] : hi[2]};
+                            }
+#ifdef MSMV_ABL_NORMW
+                            asm volatile("" ::"v"(wa[gi]), "v"(b));
+#else
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                hacc[hf][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[gi], b[t], hacc[hf][t], 0, 0, 0);
+#endif
+                        }
+                    };
+                    const int ngroups = n_pad >> 2;
+                    constexpr std::integral_constant<int, GPB> whole = {};
+                    if constexpr (HL == 2) {
+                        // the rows of batch b + 1 are requested before batch b is applied: their latency
+                        // runs beside its matrix instructions (one unconditional batch per iteration)
+                        const int nbatch = ngroups / GPB;
+                        Batch cur = load_batch(whole, 0);
+                        for (int b = 1; b < nbatch; ++b) {
+                            const Batch nxt = load_batch(whole, b * GPB);
+                            apply_batch(whole, cur, (b - 1) * GPB);
+                            cur = nxt;
+                        }
+                        apply_batch(whole, cur, (nbatch - 1) * GPB);
+                    } else {
+                        int g0 = 0;
+                        for (; g0 + GPB <= ngroups; g0 += GPB)
+                            apply_batch(whole, load_batch(whole, g0), g0);
+                        msmv_static_for<GPB - 1>([&](auto kc) {
+                            constexpr std::integral_constant<int, decltype(kc)::value + 1> part = {};
+                            if (ngroups - g0 == part.value)            // wave-uniform
+                                apply_batch(part, load_batch(part, g0), g0);
+                        });
+                    }
+                };
+                half_pass(std::integral_constant<int, 0>{}, inL, slotL, padL, h.dc0);
+                half_pass(std::integral_constant<int, 1>{}, inR, slotR, padR, h.dc0 - 4);
+            } else {
+                unsigned long long hits = __ballot(h.hit);
+#ifdef MSMV_ABL_NOHITS
+                asm volatile("" ::"v"(h.dr0), "v"(h.dc0), "v"(h.y0), "v"(h.y1), "v"(h.x0), "v"(h.x1));
+                hits = 0;
+#endif
+                const int nh = __popcll(hits);
+                if constexpr (ACC)
+                    any_hit = any_hit || nh > 0;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
+                for (int qbase = 0; qbase < nh; qbase += QC) {
+                    // every slot first becomes a null record (a valid point, all weights 0), then
+                    // hit lanes qbase .. qbase+QC-1 (in lane order) fill theirs in: the queue can
+                    // then be consumed in whole pairs without branches around the loads
+                    if (lane < QC) {
+                        typedef float rec_f32x4 __attribute__((ext_vector_type(4)));
+                        rec_f32x4 *rec = reinterpret_cast<rec_f32x4 *>(queue4 + lane * (REC_DW / 4));
+                        const rec_f32x4 head = {__int_as_float(h.pt), MULTI ? hset : 0.f, 0.f, 0.f};
+                        const rec_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        rec[0] = head;
+#pragma unroll
+                        for (int i = 1; i < REC_DW / 4; ++i)
+                            rec[i] = zero;
+                    }
+                    const unsigned slot = (unsigned)(rank - qbase);
+                    if (h.hit && slot < (unsigned)QC) {
+                        float *rec = queue + slot * REC_DW;
+                        rec[0] = __int_as_float(h.pt);
+                        rec[1] = MULTI ? hset : 0.f;
+                        rec[REC_Y0 + h.dr0] = h.y0;
+                        rec[REC_Y0 + 1 + h.dr0] = h.y1;
+                        rec[REC_X0 + h.dc0] = h.x0;
+                        rec[REC_X0 + 1 + h.dc0] = h.x1;
+                    }
+                    const int cnt = min(QC, nh - qbase);
+                    [[maybe_unused]] const int npairs = (cnt + 1) >> 1;
 
 #ifdef MSMV_ABL_NORMW
 #define MSMV_OWN_MFMA(WA, G0, G1) asm volatile("" ::"v"(WA), "v"(G0), "v"(G1));
 #else
 #define MSMV_OWN_MFMA(WA, G0, G1)                                                             \
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, G0, acc0, 0, 0, 0);       \
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, G1, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, G0, acc0, 0, 0, 0);       \
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(WA, G1, acc1, 0, 0, 0);
 #endif
 
-                if constexpr (STAGED) {
-                    // ---- the round's gradient rows: global -> LDS by direct loads, 1 KiB per wave
-                    // instruction, as a pipeline of UNITS (whole pairs of records and whole load
-                    // instructions): the staging area holds NS units, the loads of unit v + D are
-                    // issued before unit v is applied, and a counted wait leaves them in flight
-                    // (vector memory operations complete in order).  Every slot of the queue holds a
-                    // record with a valid point (null records have zero weights), so whole units are
-                    // loaded and applied without per-record tests - 0 times whatever an earlier
-                    // kernel left in LDS could be NaN, hence no row is ever left unloaded.
-                    constexpr int RPI = 64 / ROW_F4;                   // records per load instruction
-                    constexpr int UNIT_REC = RPI < 2 ? 2 : RPI;        // records per unit
-                    constexpr int IPU = UNIT_REC / RPI;                // load instructions per unit
-                    constexpr int PPU = UNIT_REC / 2;                  // pairs per unit
-                    constexpr int UNIT_F4 = UNIT_REC * ROW_F4;
-                    constexpr int NS = STAGE_F4 / UNIT_F4;             // units the staging area holds
-                    constexpr int D = NS - 1;                          // units in flight ahead of the one applied
-                    constexpr int NU = QC / UNIT_REC;                  // units per full round
-                    static_assert(NS >= 2 && NU * UNIT_REC == QC && D * IPU <= 3, "pipeline shape");
-                    const int nunits = (cnt + UNIT_REC - 1) / UNIT_REC;
-                    auto issue = [&](int v) {                          // (v is a constant after unrolling)
+                    if constexpr (STAGED) {
+                        // ---- the round's gradient rows: global -> LDS by direct loads, 1 KiB per wave
+                        // instruction, as a pipeline of UNITS (whole pairs of records and whole load
+                        // instructions): the staging area holds NS units, the loads of unit v + D are
+                        // issued before unit v is applied, and a counted wait leaves them in flight
+                        // (vector memory operations complete in order).  Every slot of the queue holds a
+                        // record with a valid point (null records have zero weights), so whole units are
+                        // loaded and applied without per-record tests - 0 times whatever an earlier
+                        // kernel left in LDS could be NaN, hence no row is ever left unloaded.
+                        constexpr int RPI = 64 / ROW_F4;                   // records per load instruction
+                        constexpr int UNIT_REC = RPI < 2 ? 2 : RPI;        // records per unit
+                        constexpr int IPU = UNIT_REC / RPI;                // load instructions per unit
+                        constexpr int PPU = UNIT_REC / 2;                  // pairs per unit
+                        constexpr int UNIT_F4 = UNIT_REC * ROW_F4;
+                        constexpr int NS = STAGE_F4 / UNIT_F4;             // units the staging area holds
+                        constexpr int D = NS - 1;                          // units in flight ahead of the one applied
+                        constexpr int NU = QC / UNIT_REC;                  // units per full round
+                        static_assert(NS >= 2 && NU * UNIT_REC == QC && D * IPU <= 3, "pipeline shape");
+                        const int nunits = (cnt + UNIT_REC - 1) / UNIT_REC;
+                        auto issue = [&](int v) {                          // (v is a constant after unrolling)
 #pragma unroll
-                        for (int j = 0; j < IPU; ++j) {
-                            const int rec = v * UNIT_REC + j * RPI + lane / ROW_F4;
-                            const int rpt = __float_as_int(queue[rec * REC_DW]);
+                            for (int j = 0; j < IPU; ++j) {
+                                const int rec = v * UNIT_REC + j * RPI + lane / ROW_F4;
+                                const int rpt = __float_as_int(queue[rec * REC_DW]);
+                                const float *go = gout;
+                                if constexpr (MULTI)
+                                    go = gout_tab[__float_as_int(queue[rec * REC_DW + 1])];
+                                const int row = PT == 4 ? rpt >> 2 : PT == 2 ? rpt >> 1 : rpt;
+                                const float *src = go + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
+                                msmv_load_to_lds_b128<MULTI && MSMV_OWN_ROWS_NT_MULTI>(src, stage + (v % NS) * UNIT_F4 + j * 64);
+                            }
+                        };
+                        // what the applying lane needs of unit v's records: its weight per pair and, for
+                        // P > 1, where in the staged row its point's channels sit
+                        auto load_q = [&](int v, float (&wa)[PPU], int (&po)[PPU]) {
+#pragma unroll
+                            for (int k2 = 0; k2 < PPU; ++k2) {
+                                const int u = v * PPU + k2;                // pair: records 2u and 2u + 1
+                                wa[k2] = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
+                                po[k2] = PT == 1 ? 0 : __float_as_int(q_pt[u * 2 * REC_DW]) & (PT - 1);
+                            }
+                        };
+                        auto apply = [&](int v, const float (&wa)[PPU], const int (&po)[PPU]) {
+                            const float *sp0 = reinterpret_cast<const float *>(stage + (v % NS) * UNIT_F4 + half * ROW_F4) +
+                                               l32 * (PT == 1 ? 1 : PT);
+#pragma unroll
+                            for (int k2 = 0; k2 < PPU; ++k2) {
+                                const float *sp = sp0 + k2 * 2 * ROW_F4 * 4;
+                                const float g0 = sp[po[k2]], g1 = sp[32 * (PT == 1 ? 1 : PT) + po[k2]];
+                                MSMV_OWN_MFMA(wa[k2], g0, g1)
+                                if constexpr (ACC)
+                                    touched = touched || wa[k2] != 0.f;
+                            }
+                        };
+                        // A round of NUV units as straight-line code (every bound a constant: no branch
+                        // keeps the compiler from moving loads up): the queue values of unit v + 1 are
+                        // fetched and the rows of unit v + D requested before unit v's rows are waited for.
+                        auto run_round = [&](auto nuv_c) {
+                            constexpr int NUV = decltype(nuv_c)::value;
+                            // (a unit of one pair fetches its queue values one unit ahead; units of
+                            // several pairs overlap within themselves and keep the registers)
+                            constexpr bool AHEAD = PPU == 1;
+                            float wa[2][PPU];
+                            int po[2][PPU];
+                            if constexpr (AHEAD)
+                                load_q(0, wa[0], po[0]);
+                            msmv_static_for<(D < NUV ? D : NUV)>([&](auto vc) { issue(decltype(vc)::value); });
+                            msmv_static_for<NUV>([&](auto vc) {
+                                constexpr int v = decltype(vc)::value;
+                                if constexpr (v + D < NUV)
+                                    issue(v + D);
+                                if constexpr (AHEAD && v + 1 < NUV)
+                                    load_q(v + 1, wa[(v + 1) & 1], po[(v + 1) & 1]);
+                                if constexpr (!AHEAD)
+                                    load_q(v, wa[v & 1], po[v & 1]);
+                                // loads issued after unit v's: those of min(D, NUV - 1 - v) units
+                                msmv_wait_vmcnt<(D < NUV - 1 - v ? D : NUV - 1 - v) * IPU>();
+                                apply(v, wa[v & 1], po[v & 1]);
+                            });
+                        };
+                        msmv_static_for<NU>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value + 1;
+                            if (nunits == k)                               // wave-uniform
+                                run_round(std::integral_constant<int, k>{});
+                        });
+                        // the next round's copies and queue writes must not overtake this round's LDS reads
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else {
+                        // P-strided gradient rows: channels l32 and l32 + 32 of the record's point, gathered
+                        // into registers one pair ahead of their use
+                        auto fetch = [&](int u, float &g0, float &g1) {
+                            const int pt = __float_as_int(q_pt[u * 2 * REC_DW]);
                             const float *go = gout;
                             if constexpr (MULTI)
-                                go = gout_tab[__float_as_int(queue[rec * REC_DW + 1])];
-                            const int row = PT == 4 ? rpt >> 2 : PT == 2 ? rpt >> 1 : rpt;
-                            const float *src = go + ((size_t)row * ROW_F4 + (lane % ROW_F4)) * 4;
-                            msmv_load_to_lds_b128<MULTI && MSMV_OWN_ROWS_NT_MULTI>(src, stage + (v % NS) * UNIT_F4 + j * 64);
-                        }
-                    };
-                    // what the applying lane needs of unit v's records: its weight per pair and, for
-                    // P > 1, where in the staged row its point's channels sit
-                    auto load_q = [&](int v, float (&wa)[PPU], int (&po)[PPU]) {
-#pragma unroll
-                        for (int k2 = 0; k2 < PPU; ++k2) {
-                            const int u = v * PPU + k2;                // pair: records 2u and 2u + 1
-                            wa[k2] = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
-                            po[k2] = PT == 1 ? 0 : __float_as_int(q_pt[u * 2 * REC_DW]) & (PT - 1);
-                        }
-                    };
-                    auto apply = [&](int v, const float (&wa)[PPU], const int (&po)[PPU]) {
-                        const float *sp0 = reinterpret_cast<const float *>(stage + (v % NS) * UNIT_F4 + half * ROW_F4) +
-                                           l32 * (PT == 1 ? 1 : PT);
-#pragma unroll
-                        for (int k2 = 0; k2 < PPU; ++k2) {
-                            const float *sp = sp0 + k2 * 2 * ROW_F4 * 4;
-                            const float g0 = sp[po[k2]], g1 = sp[32 * (PT == 1 ? 1 : PT) + po[k2]];
-                            MSMV_OWN_MFMA(wa[k2], g0, g1)
+                                go = gout_tab[__float_as_int(q_pt[u * 2 * REC_DW + 1])];
+                            const int bq = pt / geo.P, p = pt - bq * geo.P;
+                            const float *gp = go + ((size_t)bq * 64 + l32) * geo.P + p;
+                            g0 = gp[0];
+                            g1 = gp[(size_t)32 * geo.P];
+                        };
+                        float g0, g1;
+                        fetch(0, g0, g1);
+                        for (int u = 0; u < npairs; ++u) {
+                            float n0 = 0.f, n1 = 0.f;
+                            if (u + 1 < npairs)                            // wave-uniform
+                                fetch(u + 1, n0, n1);
+                            const float wa = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
+                            MSMV_OWN_MFMA(wa, g0, g1)
                             if constexpr (ACC)
-                                touched = touched || wa[k2] != 0.f;
+                                touched = touched || wa != 0.f;
+                            g0 = n0;
+                            g1 = n1;
                         }
-                    };
-                    // A round of NUV units as straight-line code (every bound a constant: no branch
-                    // keeps the compiler from moving loads up): the queue values of unit v + 1 are
-                    // fetched and the rows of unit v + D requested before unit v's rows are waited for.
-                    auto run_round = [&](auto nuv_c) {
-                        constexpr int NUV = decltype(nuv_c)::value;
-                        // (a unit of one pair fetches its queue values one unit ahead; units of
-                        // several pairs overlap within themselves and keep the registers)
-                        constexpr bool AHEAD = PPU == 1;
-                        float wa[2][PPU];
-                        int po[2][PPU];
-                        if constexpr (AHEAD)
-                            load_q(0, wa[0], po[0]);
-                        msmv_static_for<(D < NUV ? D : NUV)>([&](auto vc) { issue(decltype(vc)::value); });
-                        msmv_static_for<NUV>([&](auto vc) {
-                            constexpr int v = decltype(vc)::value;
-                            if constexpr (v + D < NUV)
-                                issue(v + D);
-                            if constexpr (AHEAD && v + 1 < NUV)
-                                load_q(v + 1, wa[(v + 1) & 1], po[(v + 1) & 1]);
-                            if constexpr (!AHEAD)
-                                load_q(v, wa[v & 1], po[v & 1]);
-                            // loads issued after unit v's: those of min(D, NUV - 1 - v) units
-                            msmv_wait_vmcnt<(D < NUV - 1 - v ? D : NUV - 1 - v) * IPU>();
-                            apply(v, wa[v & 1], po[v & 1]);
-                        });
-                    };
-                    msmv_static_for<NU>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value + 1;
-                        if (nunits == k)                               // wave-uniform
-                            run_round(std::integral_constant<int, k>{});
-                    });
-                    // the next round's copies and queue writes must not overtake this round's LDS reads
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                } else {
-                    // P-strided gradient rows: channels l32 and l32 + 32 of the record's point, gathered
-                    // into registers one pair ahead of their use
-                    auto fetch = [&](int u, float &g0, float &g1) {
-                        const int pt = __float_as_int(q_pt[u * 2 * REC_DW]);
-                        const float *go = gout;
-                        if constexpr (MULTI)
-                            go = gout_tab[__float_as_int(q_pt[u * 2 * REC_DW + 1])];
-                        const int bq = pt / geo.P, p = pt - bq * geo.P;
-                        const float *gp = go + ((size_t)bq * 64 + l32) * geo.P + p;
-                        g0 = gp[0];
-                        g1 = gp[(size_t)32 * geo.P];
-                    };
-                    float g0, g1;
-                    fetch(0, g0, g1);
-                    for (int u = 0; u < npairs; ++u) {
-                        float n0 = 0.f, n1 = 0.f;
-                        if (u + 1 < npairs)                            // wave-uniform
-                            fetch(u + 1, n0, n1);
-                        const float wa = q_wy[u * 2 * REC_DW] * q_wx[u * 2 * REC_DW];
-                        MSMV_OWN_MFMA(wa, g0, g1)
-                        if constexpr (ACC)
-                            touched = touched || wa != 0.f;
-                        g0 = n0;
-                        g1 = n1;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
 #undef MSMV_OWN_MFMA
+                }
             }
         }
     }
@@ -1086,8 +1247,13 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
             float *dstw = red[slot] + lane;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                dstw[r * 64] = acc0[r];
-                dstw[(16 + r) * 64] = acc1[r];
+                if constexpr (H16) {
+                    dstw[r * 64] = hacc[0][r >> 2][r & 3];
+                    dstw[(16 + r) * 64] = hacc[1][r >> 2][r & 3];
+                } else {
+                    dstw[r * 64] = acc0[r];
+                    dstw[(16 + r) * 64] = acc1[r];
+                }
             }
         }
         __syncthreads();
@@ -1095,8 +1261,13 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
             const float *srcw = red[slot] + lane;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc0[r] += srcw[r * 64];
-                acc1[r] += srcw[(16 + r) * 64];
+                if constexpr (H16) {
+                    hacc[0][r >> 2][r & 3] += srcw[r * 64];
+                    hacc[1][r >> 2][r & 3] += srcw[(16 + r) * 64];
+                } else {
+                    acc0[r] += srcw[r * 64];
+                    acc1[r] += srcw[(16 + r) * 64];
+                }
             }
         }
         __syncthreads();
@@ -1130,7 +1301,27 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
 #ifdef MSMV_ABL_NOSTORE
     if (nrow < 0)
 #endif
-    if constexpr (ACC) {
+    if constexpr (H16) {
+        // lane (n, r): row r of the patch, channels 4n .. 4n+3; register i of the four tiles of half hf
+        // is column 4 hf + i: one instruction stores a column of the half, 4 rows x 256 contiguous bytes
+        const int hn = lane & 15, hr = lane >> 4;
+        float *o = dst + (size_t)hr * W * 64 + 4 * hn;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = 4 * hf + i;
+                if (hr < nrow && col < ncol) {
+                    const msmv_f32x4v v = {hacc[hf][0][i], hacc[hf][1][i], hacc[hf][2][i], hacc[hf][3][i]};
+#if MSMV_OWN_NT_STORE
+                    __builtin_nontemporal_store(v, reinterpret_cast<msmv_f32x4v *>(o + col * 64));
+#else
+                    *reinterpret_cast<msmv_f32x4v *>(o + col * 64) = v;
+#endif
+                }
+            }
+        }
+    } else if constexpr (ACC) {
         if (!any_hit)
             return;                                          // wave-uniform
         // Only the pixels that received a weight are read, added to and written back: on the
@@ -1521,8 +1712,27 @@ size_t msmv_backward_owner_workspace(int B, int N, int Q, int P)
 }
 
 template <bool ACC, bool MULTI>
-static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const OwnerGeom &geo, const OwnerSets &sets)
+static void launch_owner_dfeat(int pt, dim3 grid, dim3 block, hipStream_t s, const OwnerGeom &geo, const OwnerSets &sets,
+                               int hit_loop)
 {
+    if constexpr (!ACC) {
+        if (hit_loop == 1 && pt == 1) {
+            hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, false, MULTI, 1>), grid, block, 0, s, geo, sets);
+            return;
+        }
+        if (hit_loop == 2 && pt == 1) {
+            hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, false, MULTI, 2>), grid, block, 0, s, geo, sets);
+            return;
+        }
+        if (hit_loop == 1 && pt == 2) {
+            hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, false, MULTI, 1>), grid, block, 0, s, geo, sets);
+            return;
+        }
+        if (hit_loop == 2 && pt == 2) {
+            hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, false, MULTI, 2>), grid, block, 0, s, geo, sets);
+            return;
+        }
+    }
     switch (pt) {
     case 1: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<1, ACC, MULTI>), grid, block, 0, s, geo, sets); break;
     case 2: hipLaunchKernelGGL((msmv_bwd_owner_dfeat<2, ACC, MULTI>), grid, block, 0, s, geo, sets); break;
@@ -1555,6 +1765,38 @@ static int msmv_dfeat_view_major(int nsets)
     if (forced >= 0)
         return forced;
     return nsets > 1 ? MSMV_DFEAT_VIEW_MAJOR_MULTI : MSMV_DFEAT_VIEW_MAJOR_SINGLE;
+}
+
+// Which hit loop (see the kernel's HL) for a pass over `nsets` point sets with gradient rows of kind
+// `pt` (1: contiguous rows, 2: the op's layout with two points per query).  Measured at the OPUS shapes:
+// the 16 x 16 x 4 loops win wherever rows are contiguous and for one set in the op's layout; several sets
+// in the op's layout (512-byte rows, the pass at the fabric's rate already) stay on the 32 x 32 x 2 loop.
+// OPUS_MSMV_DFEAT_HL = 0 / 1 / 2 overrides the choice for measurements.
+#ifndef MSMV_DFEAT_HL_SINGLE_ROWS
+#define MSMV_DFEAT_HL_SINGLE_ROWS 1
+#endif
+#ifndef MSMV_DFEAT_HL_SINGLE_P2
+#define MSMV_DFEAT_HL_SINGLE_P2 2
+#endif
+#ifndef MSMV_DFEAT_HL_MULTI_ROWS
+#define MSMV_DFEAT_HL_MULTI_ROWS 1
+#endif
+#ifndef MSMV_DFEAT_HL_MULTI_P2
+#define MSMV_DFEAT_HL_MULTI_P2 0
+#endif
+static int msmv_dfeat_hit_loop(int nsets, int pt)
+{
+    static const int forced = [] {
+        const char *e = getenv("OPUS_MSMV_DFEAT_HL");
+        return !e ? -1 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0));
+    }();
+    if (forced >= 0)
+        return forced;
+    if (pt == 1)
+        return nsets > 1 ? MSMV_DFEAT_HL_MULTI_ROWS : MSMV_DFEAT_HL_SINGLE_ROWS;
+    if (pt == 2)
+        return nsets > 1 ? MSMV_DFEAT_HL_MULTI_P2 : MSMV_DFEAT_HL_SINGLE_P2;
+    return 0;
 }
 
 // The d-feat pass over `sets.n` sorted point sets (each of a.qp points per batch slab).
@@ -1606,14 +1848,15 @@ static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hi
     if (ntiles > 0) {
         const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
         const int pt = a.rows ? 1 : a.P;
+        const int hl = msmv_dfeat_hit_loop(sets.n, pt);
         if (sets.n > 1 && accumulate)
-            launch_owner_dfeat<true, true>(pt, grid, block, s, geo, sets);
+            launch_owner_dfeat<true, true>(pt, grid, block, s, geo, sets, hl);
         else if (sets.n > 1)
-            launch_owner_dfeat<false, true>(pt, grid, block, s, geo, sets);
+            launch_owner_dfeat<false, true>(pt, grid, block, s, geo, sets, hl);
         else if (accumulate)
-            launch_owner_dfeat<true, false>(pt, grid, block, s, geo, sets);
+            launch_owner_dfeat<true, false>(pt, grid, block, s, geo, sets, hl);
         else
-            launch_owner_dfeat<false, false>(pt, grid, block, s, geo, sets);
+            launch_owner_dfeat<false, false>(pt, grid, block, s, geo, sets, hl);
     }
     return hipSuccess;
 }
