@@ -77,7 +77,7 @@ int fill_common(MsmvArgs &a, int L, const int *hw, int B, int C, int N, int Q, i
     }
     // point indices and grad_out element offsets are 31-bit inside the kernels
     const long long npts = (long long)B * Q * P;
-    if (npts * (long long)(C > L ? C : L) > INT_MAX || (long long)B * N > INT_MAX)
+    if (npts * (long long)(C > L ? C : L) > INT_MAX || (long long)B * N > INT_MAX || (long long)Q * P > INT_MAX)
         return OPUS_MSMV_ETOOLARGE;
     a.L = L; a.B = B; a.C = C; a.N = N; a.Q = Q; a.P = P;
     a.npts = (int)npts;

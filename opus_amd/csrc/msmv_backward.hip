@@ -451,6 +451,15 @@ msmv_bin_one(const MsmvArgs a, OwnerWs ws)
 // The patch is 4 rows x 8 columns rather than 32 pixels of one row because a point's 2x2
 // footprint then falls into 1.4 patches on average instead of 2.1: a third fewer hits.
 //
+// That is hit loop 0 of the kernel (template parameter HL).  Hit loops 1 and 2 work on the same
+// patch as two halves of 4 x 4 pixels with 16 x 16 x 4 tiles (v_mfma_f32_16x16x4_f32: four hits per
+// instruction, 4 of 16 pixels useful instead of 4 of 32), which halves the matrix-pipe time of a hit
+// - the pass is paid for per hit, and the waves of a SIMD take turns at its one matrix pipe - and
+// lets a lane load its 16 bytes of a gradient row straight into the B operand's registers and store
+// 16 contiguous bytes of d feat per instruction; see the comment in front of the kernel.  They take
+// contiguous gradient rows (row mode, P = 1) and the op's layout with P = 2; everything else
+// (P = 4, other P, ACC) and - by measurement - several sets in the op's layout run hit loop 0.
+//
 // A wave scans only the bins whose bands can reach its rows / columns; lanes that find a
 // hit (a point with a corner in the patch) write a record into a small per-wave LDS queue;
 // the wave then consumes the queue two records at a time (one per half-wave).  The kernel is
@@ -480,15 +489,15 @@ static_assert(PATCH_H * PATCH_W == 32, "a patch is the M = 32 dimension of the M
 // (measured 183 vs 198 us at OPUS-L; 2 waves: 175 us uniform but no better on crowded images)
 constexpr int OWN_WAVES = MSMV_OWN_WAVES;
 constexpr int OWN_THREADS = OWN_WAVES * 64;
-// Workgroup order of the d-feat pass, level-major (0) or view-major (1).  Measured at OPUS-L: one set
-// 159.5 / 165.0 us, six sets 621 / 686 us, six OPUS-M sets 353 / 404 us - view-major mixes the long
-// waves of a view's coarse levels with the store-bound ones of its neighbour's finest level, and two
-// views' rows still exceed the L2.
-#ifndef MSMV_DFEAT_VIEW_MAJOR_SINGLE
-#define MSMV_DFEAT_VIEW_MAJOR_SINGLE 0
+// Workgroup order of the d-feat pass: views per group (0 = all N: level-major; 1: view-major).  Measured
+// at OPUS-L: one set 159.5 / 165.0 us level- / view-major, six sets 621 / 686 us, six OPUS-M sets 353 /
+// 404 us - view-major mixes the long waves of a view's coarse levels with the store-bound ones of its
+// neighbour's finest level, and two views' rows still exceed the L2.
+#ifndef MSMV_DFEAT_VPU_SINGLE
+#define MSMV_DFEAT_VPU_SINGLE 0
 #endif
-#ifndef MSMV_DFEAT_VIEW_MAJOR_MULTI
-#define MSMV_DFEAT_VIEW_MAJOR_MULTI 0
+#ifndef MSMV_DFEAT_VPU_MULTI
+#define MSMV_DFEAT_VPU_MULTI 0
 #endif
 #ifndef MSMV_OWN_SPLIT_HITS
 #define MSMV_OWN_SPLIT_HITS 64                   // expected hits per wave above which a level's patches are shared
@@ -521,16 +530,16 @@ static_assert(sizeof(OwnerLevel) == 64, "one 64-byte scalar load per level");
 
 struct OwnerGeom {
     OwnerLevel lv[MSMV_MAX_LEVELS];
-    // workgroups of a batch slab are ordered [view][level, coarse first][tile] (view_major) or
-    // [level, coarse first][view][tile]: seg_end[k] is the end of the k-th level in that order
-    // (level L-1-k) within a view or within the slab; INT_MAX from the last level on
+    // workgroups of a batch slab are ordered [view group][level, coarse first][view][tile], a group
+    // being vpu views (N: level-major, 1: view-major): seg_end[k] is the end of the k-th level in that
+    // order (level L-1-k) within a group; INT_MAX from the last level on
     int seg_end[MSMV_MAX_LEVELS];
     MsmvDiv div_tiles_per_b;
     int tiles_per_b;            // N * sum over levels of tiles
     int L, N, qp, P;
-    int view_major;
-    int tiles_per_view;         // sum over levels of tiles
-    MsmvDiv div_tiles_per_view;
+    int vpu;                    // views per group: a divisor of N
+    int tiles_per_group;        // vpu * sum over levels of tiles
+    MsmvDiv div_tiles_per_group;
 };
 
 // The sorted point sets one d-feat launch accumulates: normally one (this call's), several when
@@ -674,8 +683,8 @@ __device__ unsigned long long *msmv_dbg_buf;
 #define MSMV_DBG_HSTAMP(K)
 #endif
 
-// H16: the hit loop on 16 x 16 x 4 matrix tiles (v_mfma_f32_16x16x4_f32, 32 matrix-pipe cycles for
-// four hits x 16 pixels x 16 channels) instead of 32 x 32 x 2 ones.  The patch is worked on as two
+// Hit loops 1 and 2 (HL != 0): 16 x 16 x 4 matrix tiles (v_mfma_f32_16x16x4_f32, 32 matrix-pipe cycles
+// for four hits x 16 pixels x 16 channels) instead of 32 x 32 x 2 ones.  The patch is worked on as two
 // HALVES of 4 x 4 pixels (columns 0..3 / 4..7): a hit is queued for the half - or the two halves - its
 // footprint reaches (10 / 9 halves per hit), and a group of four queued hits costs four matrix
 // instructions, one per tile of 16 channel quadruples: 35 matrix-pipe cycles per hit instead of 64.
@@ -685,7 +694,8 @@ __device__ unsigned long long *msmv_dbg_buf;
 // row's 256 bytes by 16 neighbouring lanes, no staging in LDS.  Accumulator register i of tile t
 // in lane (n, r) is pixel (row r, column i) of the half, channel 4n + t: the four tiles' registers
 // i form 16 contiguous bytes of d feat, and one store instruction writes a column of the half -
-// 4 rows x 256 contiguous bytes.  Row mode / P <= 2, no ACC.
+// 4 rows x 256 contiguous bytes.  The wave's queue (64 records of 64 bytes: the row's address and
+// the separable weight tables for the half) lives in what hit loop 0 uses as its staging area.
 // HL (hit loop): 0 = 32 x 32 x 2 tiles over whole patches; 1 = 16 x 16 x 4 tiles over half patches, the
 // rows of two groups of four hits requested together, then both groups applied; 2 = the same tiles, one
 // group at a time with the next group's rows requested before this group is applied.
@@ -746,18 +756,15 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
         __syncthreads();
     }
 
-    // ---- which patch: logical order [b][view][level, coarse first][tile][wave / K] (view_major: a
-    // view's gradient rows and bin entries are then what an XCD's L2 has to hold from one level of the
-    // view to the next - with several point sets a whole slab's no longer fit) or
-    // [b][level, coarse first][view][tile][wave / K]
+    // ---- which patch: logical order [b][view group][level, coarse first][view][tile][wave / K].  A
+    // group is geo.vpu views: all N of them (level-major: one phase per level and slab), one (view-major:
+    // a view's gradient rows and bin entries are then what an XCD's L2 has to hold from one level to
+    // the next - with several point sets a whole slab's no longer fit) or a divisor of N in between
     int id = msmv_xcd_remap(blockIdx.x, gridDim.x);
     const int b = (int)msmv_div((uint32_t)id, geo.div_tiles_per_b);
     id -= b * geo.tiles_per_b;
-    int view_of_id = 0;
-    if (geo.view_major) {
-        view_of_id = (int)msmv_div((uint32_t)id, geo.div_tiles_per_view);
-        id -= view_of_id * geo.tiles_per_view;
-    }
+    const int vgroup = (int)msmv_div((uint32_t)id, geo.div_tiles_per_group);
+    id -= vgroup * geo.tiles_per_group;
     int k = 0, seg_start = 0;
 #pragma unroll
     for (int j = 0; j < MSMV_MAX_LEVELS - 1; ++j) {          // (seg_end is INT_MAX from the last level on)
@@ -774,8 +781,9 @@ msmv_bwd_owner_dfeat(const OwnerGeom geo, const OwnerSets sets)
     id -= seg_start;
     const OwnerLevel G = geo.lv[l];
     const int N = geo.N;
-    const int view = geo.view_major ? view_of_id : (int)msmv_div((uint32_t)id, G.div_tiles);
-    const int tile_idx = geo.view_major ? id : id - view * G.tiles;
+    const int view_in_group = (int)msmv_div((uint32_t)id, G.div_tiles);
+    const int view = vgroup * geo.vpu + view_in_group;
+    const int tile_idx = id - view_in_group * G.tiles;
     const int klog = G.split_log2;
     const int K = 1 << klog;                                 // waves sharing a patch
     const int sub = wave & (K - 1);                          // this wave's share: entries sub, sub + K, ...
@@ -1754,17 +1762,19 @@ static OwnerWs owner_ws_of(const MsmvArgs &a, void *workspace)
     return ws;
 }
 
-// Workgroup order of the d-feat pass: view-major or level-major (see the kernel).  OPUS_MSMV_DFEAT_ORDER
-// = "view" / "level" overrides the default for measurements.
-static int msmv_dfeat_view_major(int nsets)
+// Workgroup order of the d-feat pass (see the kernel): views per group - N = level-major, 1 = view-major.
+// OPUS_MSMV_DFEAT_ORDER = "view" / "level" / a number of views overrides the default for measurements; a
+// value that does not divide N falls back to N.
+static int msmv_dfeat_views_per_group(int nsets, int N)
 {
     static const int forced = [] {
         const char *e = getenv("OPUS_MSMV_DFEAT_ORDER");
-        return !e ? -1 : (e[0] == 'v' ? 1 : 0);
+        return !e ? -1 : (e[0] == 'v' ? 1 : (e[0] == 'l' ? 0 : atoi(e)));
     }();
-    if (forced >= 0)
-        return forced;
-    return nsets > 1 ? MSMV_DFEAT_VIEW_MAJOR_MULTI : MSMV_DFEAT_VIEW_MAJOR_SINGLE;
+    int vpu = forced >= 0 ? forced : (nsets > 1 ? MSMV_DFEAT_VPU_MULTI : MSMV_DFEAT_VPU_SINGLE);
+    if (vpu < 1 || vpu > N || N % vpu != 0)
+        vpu = N;
+    return vpu;
 }
 
 // Which hit loop (see the kernel's HL) for a pass over `nsets` point sets with gradient rows of kind
@@ -1828,13 +1838,13 @@ static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hi
         per_view += g.tiles;
     }
     // workgroup order within a batch slab (or within a view of it): coarse level first
-    geo.view_major = msmv_dfeat_view_major(sets.n);
-    geo.tiles_per_view = per_view;
-    geo.div_tiles_per_view = msmv_make_div(per_view);
+    geo.vpu = msmv_dfeat_views_per_group(sets.n, a.N);
+    geo.tiles_per_group = per_view * geo.vpu;
+    geo.div_tiles_per_group = msmv_make_div(geo.tiles_per_group);
     long long end = 0;
     for (int k = 0; k < MSMV_MAX_LEVELS; ++k) {
         if (k < a.L - 1) {
-            end += (long long)geo.lv[a.L - 1 - k].tiles * (geo.view_major ? 1 : a.N);
+            end += (long long)geo.lv[a.L - 1 - k].tiles * geo.vpu;
             geo.seg_end[k] = (int)end;
         } else {
             geo.seg_end[k] = 0x7FFFFFFF;

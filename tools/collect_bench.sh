@@ -37,6 +37,7 @@ run decoder-L_queries --workload decoder-L --points queries --steps 100 --no-cpu
 run chain-L --workload chain-L --steps 100 --no-cpu-baseline       # the whole sampling chain of a training step
 run chain-L_queries --workload chain-L --points queries --steps 100 --no-cpu-baseline
 run chain-T --workload chain-T --steps 100 --no-cpu-baseline
+run chain-L_no-checkpoint --workload chain-L --no-checkpoint --steps 100 --no-cpu-baseline   # one forward per layer (288 GB of HBM: nothing to recompute)
 run infer-L --workload infer-L --steps 200 --no-cpu-baseline       # ... and of an inference frame
 run infer-L_queries --workload infer-L --points queries --steps 200 --no-cpu-baseline
 run train-M_group --workload train-M --steps 50 --init-group --no-cpu-baseline   # RCCL in a group of one: schedule + exposed time
