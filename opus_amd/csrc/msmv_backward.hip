@@ -1781,7 +1781,8 @@ static int msmv_dfeat_views_per_group(int nsets, int N)
 // `pt` (1: contiguous rows, 2: the op's layout with two points per query).  Measured at the OPUS shapes:
 // the 16 x 16 x 4 loops win wherever rows are contiguous and for one set in the op's layout; several sets
 // in the op's layout (512-byte rows, the pass at the fabric's rate already) stay on the 32 x 32 x 2 loop.
-// OPUS_MSMV_DFEAT_HL = 0 / 1 / 2 overrides the choice for measurements.
+// There, loop 2 is ahead while the finest level's patches expect few hits (OPUS-S / M: 2-5 %) and behind
+// when they expect many (OPUS-L: 3-6 %).  OPUS_MSMV_DFEAT_HL = 0 / 1 / 2 overrides the choice for measurements.
 #ifndef MSMV_DFEAT_HL_SINGLE_ROWS
 #define MSMV_DFEAT_HL_SINGLE_ROWS 1
 #endif
@@ -1794,7 +1795,13 @@ static int msmv_dfeat_views_per_group(int nsets, int N)
 #ifndef MSMV_DFEAT_HL_MULTI_P2
 #define MSMV_DFEAT_HL_MULTI_P2 0
 #endif
-static int msmv_dfeat_hit_loop(int nsets, int pt)
+#ifndef MSMV_DFEAT_HL_MULTI_P2_SPARSE
+#define MSMV_DFEAT_HL_MULTI_P2_SPARSE 2          // ... while a patch of the finest level expects fewer hits than
+#endif
+#ifndef MSMV_DFEAT_HL_MULTI_P2_SPARSE_HITS
+#define MSMV_DFEAT_HL_MULTI_P2_SPARSE_HITS 30    // this (six OPUS-M layers: 19, six OPUS-L layers: 38)
+#endif
+static int msmv_dfeat_hit_loop(int nsets, int pt, double finest_hits_per_patch)
 {
     static const int forced = [] {
         const char *e = getenv("OPUS_MSMV_DFEAT_HL");
@@ -1804,8 +1811,10 @@ static int msmv_dfeat_hit_loop(int nsets, int pt)
         return forced;
     if (pt == 1)
         return nsets > 1 ? MSMV_DFEAT_HL_MULTI_ROWS : MSMV_DFEAT_HL_SINGLE_ROWS;
+    if (pt == 2 && nsets > 1)
+        return finest_hits_per_patch < MSMV_DFEAT_HL_MULTI_P2_SPARSE_HITS ? MSMV_DFEAT_HL_MULTI_P2_SPARSE : MSMV_DFEAT_HL_MULTI_P2;
     if (pt == 2)
-        return nsets > 1 ? MSMV_DFEAT_HL_MULTI_P2 : MSMV_DFEAT_HL_SINGLE_P2;
+        return MSMV_DFEAT_HL_SINGLE_P2;
     return 0;
 }
 
@@ -1858,7 +1867,8 @@ static hipError_t launch_dfeat_sets(const MsmvArgs &a, const OwnerSets &sets, hi
     if (ntiles > 0) {
         const dim3 grid((unsigned)ntiles), block(OWN_THREADS);
         const int pt = a.rows ? 1 : a.P;
-        const int hl = msmv_dfeat_hit_loop(sets.n, pt);
+        const double finest_hits = 1.4 * (double)a.qp * sets.n / ((double)a.N * geo.lv[0].patches);
+        const int hl = msmv_dfeat_hit_loop(sets.n, pt, finest_hits);
         if (sets.n > 1 && accumulate)
             launch_owner_dfeat<true, true>(pt, grid, block, s, geo, sets, hl);
         else if (sets.n > 1)
