@@ -20,7 +20,8 @@ struct ProjDims {
     int B, Q, T, G, P, L, N;
     int shared;          // the T frames share one set of points / weights: sources are [B,Q,G,P,*]
     float inv_w, inv_h, image_w, image_h, eps;
-    long long npts;      // B*T*G*Q*P
+    long long npts;      // B*T*G*Q*P (the host guarantees < 2^31: slots are split with 32-bit magic divisions)
+    MsmvDiv div_p, div_q, div_g, div_t;
 };
 
 // index math shared by both directions: point slot `idx` of the op's loc tensor
@@ -31,15 +32,15 @@ struct ProjIndex {
     size_t dst_w;        // element offset in the op's weights [B*G*T,Q,P,L]
 };
 
-__device__ __forceinline__ ProjIndex proj_index(long long idx, const ProjDims &d)
+__device__ __forceinline__ ProjIndex proj_index(uint32_t idx, const ProjDims &d)
 {
     ProjIndex r;
-    long long x = idx;
-    r.p = (int)(x % d.P); x /= d.P;
-    r.q = (int)(x % d.Q); x /= d.Q;
-    r.g = (int)(x % d.G); x /= d.G;
-    r.t = (int)(x % d.T); x /= d.T;
-    r.b = (int)x;
+    uint32_t x = idx, y = msmv_div(x, d.div_p);
+    r.p = (int)(x - y * d.P); x = y; y = msmv_div(x, d.div_q);
+    r.q = (int)(x - y * d.Q); x = y; y = msmv_div(x, d.div_g);
+    r.g = (int)(x - y * d.G); x = y; y = msmv_div(x, d.div_t);
+    r.t = (int)(x - y * d.T);
+    r.b = (int)y;
     if (d.shared) {
         const size_t e = (((size_t)r.b * d.Q + r.q) * d.G + r.g) * d.P + r.p;
         r.src_pt = e * 3;
@@ -73,7 +74,7 @@ msmv_project_pack_fwd(const float *__restrict__ pts, const float *__restrict__ s
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= d.npts)
         return;
-    const ProjIndex ix = proj_index(idx, d);
+    const ProjIndex ix = proj_index((uint32_t)idx, d);
     const float x = pts[ix.src_pt], y = pts[ix.src_pt + 1], z = pts[ix.src_pt + 2];
     const float *M = occ2img + ((size_t)ix.b * d.T * d.N + (size_t)ix.t * d.N) * 16;
 
@@ -115,7 +116,7 @@ msmv_project_pack_bwd(const float *__restrict__ dloc, const float *__restrict__ 
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= d.npts)
         return;
-    const ProjIndex ix = proj_index(idx, d);
+    const ProjIndex ix = proj_index((uint32_t)idx, d);
     const float x = pts[ix.src_pt], y = pts[ix.src_pt + 1], z = pts[ix.src_pt + 2];
     int view = (int)roundf(loc[(size_t)idx * 3 + 2] * (float)(d.N - 1));
     view = min(max(view, 0), d.N - 1);
@@ -148,11 +149,11 @@ msmv_project_pack_bwd_shared(const float *__restrict__ dloc, const float *__rest
     const long long nsrc = (long long)d.B * d.Q * d.G * d.P;
     if (e >= nsrc)
         return;
-    long long r = e;
-    const int p = (int)(r % d.P); r /= d.P;
-    const int g = (int)(r % d.G); r /= d.G;
-    const int q = (int)(r % d.Q);
-    const int b = (int)(r / d.Q);
+    uint32_t r = (uint32_t)e, r1 = msmv_div(r, d.div_p);
+    const int p = (int)(r - r1 * d.P); r = r1; r1 = msmv_div(r, d.div_g);
+    const int g = (int)(r - r1 * d.G); r = r1; r1 = msmv_div(r, d.div_q);
+    const int q = (int)(r - r1 * d.Q);
+    const int b = (int)r1;
     const float x = pts[e * 3], y = pts[e * 3 + 1], z = pts[e * 3 + 2];
     float gx = 0.f, gy = 0.f, gz = 0.f;
     float gw[MSMV_MAX_LEVELS];
@@ -200,6 +201,7 @@ ProjDims make_dims(int B, int Q, int T, int G, int P, int L, int N, float image_
     d.inv_w = 1.f / image_w; d.inv_h = 1.f / image_h;
     d.eps = eps;
     d.npts = (long long)B * T * G * Q * P;
+    d.div_p = msmv_make_div(P); d.div_q = msmv_make_div(Q); d.div_g = msmv_make_div(G); d.div_t = msmv_make_div(T);
     return d;
 }
 
