@@ -774,3 +774,63 @@ def test_where_a_non_finite_gradient_lands(wr):
         only[b0, q0, p0] = True
         assert not (bad & ~only).any(), f"{what}: other points stay finite"
         assert_close(np.where(bad, 0, o), np.where(bad, 0, a), GRAD_RTOL, what)
+
+
+# ---------------------------------------------------------------- every hit loop of the d-feat kernel
+_HIT_LOOP_CHECK = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, {tests!r} + "/golden")
+sys.path.insert(0, {tests!r})
+sys.path.insert(0, {root!r})
+from helpers import GRAD_RTOL, REAL_LEVELS, assert_close, random_case
+from opus_amd.csrc import wrapper as wr
+from opus_amd import _lib
+from oracle import msmv_oracle as oracle
+oracle.build()
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+for levels, P, Q in ((REAL_LEVELS, 1, 300), (REAL_LEVELS, 2, 211), (REAL_LEVELS + [(4, 11)], 2, 97)):
+    # one set, in the op's layout
+    feats, loc, w, g = random_case(900 + P + Q, levels, B=2, N=6, C=64, Q=Q, P=P)
+    ref_df, _, _ = oracle.backward(g, feats, loc, w)
+    f, l, ww = [dev(x) for x in feats], dev(loc), dev(w)
+    df, _, _ = wr.msmv_backward(dev(g), f, l, ww, algo="owner")
+    for i, d in enumerate(df):
+        assert_close(d.cpu().numpy(), ref_df[i], GRAD_RTOL, "dfeat%d, one set, P=%d" % (i, P))
+    # three sets in one pass (deferred d feats)
+    sets = [random_case(1900 + P + Q + k, levels, B=2, N=6, C=64, Q=Q, P=P) for k in range(3)]
+    total = None
+    gs, wss = [], []
+    for _, lo, we, go in sets:
+        rdf, _, _ = oracle.backward(go, feats, lo, we)
+        total = rdf if total is None else [a + b for a, b in zip(total, rdf)]
+        lo_d, we_d, go_d = dev(lo), dev(we), dev(go)
+        ws = torch.empty(wr.backward_workspace_bytes(f, lo_d, we_d, _lib.BWD_OWNER), dtype=torch.uint8, device="cuda")
+        wr.msmv_backward_into(go_d, f, lo_d, we_d, None, torch.empty_like(lo_d), torch.empty_like(we_d), ws,
+                              flags=_lib.BWD_OWNER | _lib.BWD_STAGE_BIN | _lib.BWD_STAGE_GATHER)
+        gs.append(go_d)
+        wss.append(ws)
+    out = [torch.full_like(x, float("nan")) for x in f]
+    wr.msmv_dfeat_multi(gs, wss, f, Q, P, out)
+    torch.cuda.synchronize()
+    for i, d in enumerate(out):
+        assert_close(d.cpu().numpy(), total[i], GRAD_RTOL, "dfeat%d, three sets, P=%d" % (i, P))
+print("hit loop ok")
+"""
+
+
+@pytest.mark.parametrize("hit_loop", ["0", "1", "2"])
+def test_every_hit_loop_of_the_dfeat_kernel(hit_loop):
+    """The d-feat kernel picks one of three hit loops by layout and size; OPUS_MSMV_DFEAT_HL (read once
+    per process) forces one wherever it applies.  Each loop, forced in a process of its own, against the
+    oracle: one set and three sets in one pass, P = 1 and 2, 4 and 5 levels."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    env = dict(os.environ, OPUS_MSMV_DFEAT_HL=hit_loop)
+    p = subprocess.run([sys.executable, "-c", _HIT_LOOP_CHECK.format(tests=here, root=root)], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "hit loop ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
