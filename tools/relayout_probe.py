@@ -1,5 +1,5 @@
-"""Times opus_msmv_relayout and its inverse per pyramid level at the OPUS-L shapes (B=1, T=8, N=6,
-G=4, C=64, 640 x 1600 input at strides 8..64): µs and TB/s of read + written bytes per launch."""
+"""Times opus_msmv_relayout and its inverse per pyramid level (B=1, T=8, N=6, G=4, C=64; levels of a
+640 x 1600 input at strides 8..64, 1.5 x the maps of the benchmark's 256 x 704 input): µs and TB/s of read + written bytes per launch."""
 import ctypes
 import sys
 
